@@ -1,0 +1,203 @@
+/*
+ * pt_hip.h -- C ABI of the MI355X ray-casting library (libpt_hip.so).
+ *
+ * This is the boundary a host program binds instead of the reference's CPU ray caster.
+ * The reference has no FFI of its own; each entry point below names the C++ call it
+ * stands in for (paths relative to the reference tree).
+ *
+ * Conventions: every function returns 0 on success or a negative PT_ERR_* code, never
+ * throws and never aborts; pt_last_error() returns a thread-local message for the last
+ * failure.  Host arrays passed in are copied before the call returns; the caller keeps
+ * ownership.  Handles are not internally locked: one host thread drives one handle at a
+ * time.  Pointers named d_* are device pointers on the handle's device.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK               0
+#define PT_ERR_INVALID     -1   /* bad argument (null pointer, size out of range, malformed tree) */
+#define PT_ERR_DEVICE      -2   /* HIP runtime error; message has the HIP error string          */
+#define PT_ERR_NO_DEVICE   -3   /* no usable GPU                                                */
+#define PT_ERR_LIMIT       -4   /* scene or request exceeds a documented limit                  */
+
+/* ---- flattened scene (host side produces it; see pt_host.h) ------------------------- */
+
+/* Child reference: bit 31 set = leaf, bits 30..26 = triangle count (1..31, or 0 when the
+ * count is stored in the first triangle's `leaf_count`), bits 25..0 = index of the leaf's
+ * first triangle.  Bit 31 clear = index of an interior node. */
+#define PT_REF_LEAF        0x80000000u
+#define PT_REF_COUNT_SHIFT 26
+#define PT_REF_START_MASK  0x03ffffffu
+#define PT_MAX_TRIANGLES   (1u << 26)
+#define PT_MAX_TREE_DEPTH  20      /* interior levels above any leaf; reference caps at 19 (kdtree.cpp:13) */
+#define PT_MAX_LIGHTS      16
+
+/* One interior node of the reference's tree (kdTreeNode, kdtree.h:19-36), holding the
+ * AABBs of BOTH children so a visit needs one 64-byte load.  The node's own box lives in
+ * its parent (the root's in pt_flat_scene). */
+typedef struct pt_flat_node {
+    float    lo_min[3], lo_max[3];   /* low_side->aabb   */
+    float    hi_min[3], hi_max[3];   /* high_side->aabb  */
+    uint32_t lo_ref, hi_ref;
+    uint32_t axis;                   /* split_axis       */
+    uint32_t pad;
+} pt_flat_node;                      /* 64 bytes */
+
+/* Intersection record, leaf order: what Triangle::ray_test reads (utils.cpp:138-163). */
+typedef struct pt_tri_isect {
+    float    p0[3], e1[3], e2[3];    /* points[0], edge01, edge02 */
+    uint32_t mesh_index;             /* index of this triangle in the input mesh */
+    uint32_t leaf_count;             /* triangles in this leaf; valid in a leaf's first record */
+    uint32_t pad;
+} pt_tri_isect;                      /* 48 bytes */
+
+/* Shading record, same order: what Integrator::cast_ray reads after a hit
+ * (integrator.cpp:66-74, utils.cpp:165-170). */
+typedef struct pt_tri_shade {
+    float normal[3];  float plane;   /* Triangle::normal; mean of normal.dot(points[i]) */
+    float base_n[3];  float pad0;    /* base_normal */
+    float u_n[3];     float pad1;    /* u_normal    */
+    float v_n[3];     float pad2;    /* v_normal    */
+} pt_tri_shade;                      /* 64 bytes */
+
+typedef struct pt_flat_scene {
+    uint64_t            n_nodes;     /* interior nodes                                  */
+    uint64_t            n_tris;
+    const pt_flat_node* nodes;
+    const pt_tri_isect* tris;
+    const pt_tri_shade* shade;
+    uint32_t            root_ref;    /* leaf ref when the whole mesh is one leaf        */
+    uint32_t            max_depth;   /* interior levels on the longest root-to-leaf path */
+    float               root_min[3], root_max[3];
+} pt_flat_scene;
+
+/* ---- scene --------------------------------------------------------------------------- */
+
+typedef struct pt_scene pt_scene;
+
+int  pt_device_count(int* n);
+/* Uploads the flattened tree; immutable afterwards.  Replaces the device-less
+ * `new kdTree(mesh)` result that Scene holds (integrator.cpp:30).  The arrays are checked
+ * (child references in range, depth <= PT_MAX_TREE_DEPTH, leaf ranges inside the triangle
+ * array) so that a malformed tree is rejected here instead of faulting a kernel. */
+int  pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out);
+void pt_scene_destroy(pt_scene* s);
+
+/* ---- ray casting --------------------------------------------------------------------- */
+
+/* Closest hit for n rays: kdTree::ray_test (kdtree.cpp:577-580) applied to each ray.
+ * Directions are used as given (the reference normalises in Ray's constructor, not here).
+ * tri_index = mesh triangle index or -1; t,u,v are 0 on a miss.  Visit order, tie-breaking
+ * and arithmetic follow kdTreeNode::ray_test (kdtree.cpp:271-396) exactly.
+ * Host-pointer form: arrays of n floats each, copied to and from the device. */
+int pt_raycast_closest(pt_scene* s, uint64_t n,
+                       const float* ox, const float* oy, const float* oz,
+                       const float* dx, const float* dy, const float* dz,
+                       int32_t* tri_index, float* t, float* u, float* v);
+/* Device-pointer form (inputs and outputs already resident in HBM); asynchronous on the
+ * scene's stream, ordered after earlier calls on the same scene; pt_scene_sync() waits. */
+int pt_raycast_closest_dev(pt_scene* s, uint64_t n,
+                           const float* d_ox, const float* d_oy, const float* d_oz,
+                           const float* d_dx, const float* d_dy, const float* d_dz,
+                           int32_t* d_tri_index, float* d_t, float* d_u, float* d_v);
+
+/* Light visibility as the integrator evaluates it (integrator.cpp:124-129): visible = 1 iff
+ * the unbounded ray hits nothing or the barycentric v of its closest hit exceeds dist
+ * (the reference passes its out-parameters in the order u,v,t). */
+int pt_raycast_shadow(pt_scene* s, uint64_t n,
+                      const float* ox, const float* oy, const float* oz,
+                      const float* dx, const float* dy, const float* dz,
+                      const float* dist, uint8_t* visible);
+int pt_raycast_shadow_dev(pt_scene* s, uint64_t n,
+                          const float* d_ox, const float* d_oy, const float* d_oz,
+                          const float* d_dx, const float* d_dy, const float* d_dz,
+                          const float* d_dist, uint8_t* d_visible);
+
+int pt_scene_sync(pt_scene* s);
+
+/* Milliseconds the GPU spent in this scene's kernels of one class since the last call with
+ * reset != 0, measured with HIP events on the scene's stream, and the number of launches.
+ * Classes: 0 closest-hit, 1 shadow, 2 generate, 3 shade, 4 accumulate. */
+#define PT_KERNEL_CLOSEST    0
+#define PT_KERNEL_SHADOW     1
+#define PT_KERNEL_GENERATE   2
+#define PT_KERNEL_SHADE      3
+#define PT_KERNEL_ACCUMULATE 4
+#define PT_KERNEL_CLASSES    5
+int pt_scene_kernel_time(pt_scene* s, int kernel_class, int reset, double* ms, uint64_t* launches);
+
+/* ---- film and rendering -------------------------------------------------------------- */
+
+/* The fields of Scene that Integrator::perform_pass reads at every pass
+ * (integrator.h:24-29); callers may change them between calls (cli_render.cpp:92-100). */
+typedef struct pt_camera {
+    float origin[3];
+    float direction[3];
+    float up[3];
+    float image_plane_width;
+    float plane_of_focus_distance;
+    float dof_dispersion;
+    float sky_color[3];
+} pt_camera;
+
+typedef struct pt_light {        /* Light, integrator.h:15-18 */
+    float position[3];
+    float color[3];
+} pt_light;
+
+/* n_samples passes of PassDescriptor(x, y, w, h) (integrator.h:35-43), using sample indices
+ * first_sample .. first_sample + n_samples - 1 of the random stream. */
+typedef struct pt_tile_pass {
+    int32_t  x, y, w, h;         /* w or h = -1: to the edge, as PassDescriptor::clamp_bounds */
+    uint32_t first_sample;
+    uint32_t n_samples;
+} pt_tile_pass;
+
+typedef struct pt_render_stats {
+    uint64_t camera_samples;
+    uint64_t closest_rays;       /* what `rays_cast++` (kdtree.cpp:578) would count from :57  */
+    uint64_t shadow_rays;        /* ... and from integrator.cpp:127                            */
+    double   gpu_ms;             /* GPU time of this call, HIP events on the scene's stream    */
+} pt_render_stats;
+
+typedef struct pt_film pt_film;
+
+/* Device-resident Canvas (canvas.h:8-27): per pixel the RGB energy sum and the pass count,
+ * stored as 4 floats {r, g, b, passes} so one sum-reduce combines films of several GPUs
+ * (Canvas::add_from, canvas.cpp:47-52).  If d_external is not NULL the film uses that
+ * device buffer (width*height*4 floats, owned by the caller) instead of allocating. */
+int  pt_film_create(pt_scene* s, int width, int height, float* d_external, pt_film** out);
+void pt_film_destroy(pt_film* f);
+int  pt_film_zero(pt_film* f);                         /* Canvas::zero, canvas.cpp:19-25 */
+float* pt_film_device_ptr(pt_film* f);
+/* Copies out Canvas::pixels (W*H*3) and Canvas::per_pixel_passes (W*H); waits for rendering. */
+int  pt_film_read(pt_film* f, float* rgb_sum, int32_t* per_pixel_passes);
+
+/* Integrator::perform_pass (integrator.cpp:211-275) for every listed tile pass, as a
+ * wavefront path tracer.  Asynchronous unless stats != NULL (then it waits and fills stats).
+ * Pixels touched by several entries are accumulated in list order. */
+int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, int n_lights,
+                     const pt_tile_pass* passes, int n_passes, uint64_t seed,
+                     pt_render_stats* stats);
+
+/* The jittered camera rays of sample `sample` for the rectangle, row-major, as SoA device
+ * arrays of w*h floats: what integrator.cpp:248-259 builds before calling cast_ray.
+ * jittered = 0 gives Integrator::get_ray_for_pixel (integrator.cpp:197-209) instead. */
+int pt_camera_rays_dev(pt_scene* s, const pt_camera* cam, int width, int height,
+                       int x, int y, int w, int h, int jittered, uint32_t sample, uint64_t seed,
+                       float* d_ox, float* d_oy, float* d_oz, float* d_dx, float* d_dy, float* d_dz);
+
+const char* pt_last_error(void);
+/* Version string of the library and the GPU architecture it was compiled for. */
+const char* pt_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

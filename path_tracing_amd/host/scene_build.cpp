@@ -1,0 +1,464 @@
+/*
+ * scene_build.cpp -- host-side scene preparation for the GPU ray caster.
+ *
+ * Produces, on the CPU, exactly the tree the reference builds (kdTreeNode::kdTreeNode,
+ * reference kdtree.cpp:32-262) and flattens it into the arrays of pt_flat_scene.  The
+ * construction differs from the reference's: instead of six std::vector<int> per node it
+ * keeps six global index arrays and gives every node a contiguous segment of each, split
+ * in place by a stable partition.  Because the partition is stable and the low part comes
+ * first, the final by-minimum-x array is the concatenation of all leaves in left-to-right
+ * order, i.e. it IS the leaf-order triangle permutation, and a leaf is just (begin, count).
+ *
+ * All float results that the GPU later consumes (edges, normals, plane parameters, boxes)
+ * are computed here in strict binary32 in the operation order documented below; build with
+ * -ffp-contract=off and without fast-math.
+ *
+ * 3-vector conventions (the evaluation order Eigen 3.3/3.4 uses for fixed-size 3-vectors):
+ * dot = a0*b0 + (a1*b1 + a2*b2); normalize divides each component by sqrtf(dot(a,a)) and
+ * leaves a zero vector unchanged.
+ */
+#include "pt_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct F3 { float x, y, z; };
+inline F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+inline F3 sub(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline F3 add(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline float dot3(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+inline F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline F3 unit(F3 a) {
+    float z = dot3(a, a);
+    if (z > 0.0f) { float n = sqrtf(z); return f3(a.x / n, a.y / n, a.z / n); }
+    return a;
+}
+inline float sel_min(float x, float y) { return x < y ? x : y; } /* reference utils.h:29-31 */
+inline float sel_max(float x, float y) { return x < y ? y : x; } /* reference utils.h:33-35 */
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+/* Mesh in SoA form: what the builder and the flattener read. */
+struct Mesh {
+    int64_t n = 0;
+    std::vector<F3> p0, p1, p2, normal, vn0, vn1, vn2; /* corners, face normal, vertex normals */
+    std::vector<float> bmin[3], bmax[3];               /* triangle AABBs per axis */
+};
+
+/* Triangle::Triangle (reference utils.cpp:116-129). */
+void mesh_from_soup(Mesh& m, const float* v, int64_t n) {
+    m.n = n;
+    m.p0.resize(n); m.p1.resize(n); m.p2.resize(n); m.normal.resize(n);
+    for (int a = 0; a < 3; a++) { m.bmin[a].resize(n); m.bmax[a].resize(n); }
+    for (int64_t i = 0; i < n; i++) {
+        const float* q = v + 9 * i;
+        F3 a = f3(q[0], q[1], q[2]), b = f3(q[3], q[4], q[5]), c = f3(q[6], q[7], q[8]);
+        m.p0[i] = a; m.p1[i] = b; m.p2[i] = c;
+        m.normal[i] = unit(cross3(sub(b, a), sub(c, a)));
+        const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
+        for (int k = 0; k < 3; k++) {
+            m.bmin[k][i] = sel_min(sel_min(pa[k], pb[k]), pc[k]);
+            m.bmax[k][i] = sel_max(sel_max(pa[k], pb[k]), pc[k]);
+        }
+    }
+}
+
+struct VKey {
+    uint32_t a, b, c;
+    bool operator==(const VKey& o) const { return a == o.a && b == o.b && c == o.c; }
+};
+struct VKeyHash {
+    size_t operator()(const VKey& k) const {
+        uint64_t h = k.a * 0x9E3779B97F4A7C15ull;
+        h ^= (h >> 32); h += k.b; h *= 0xC2B2AE3D27D4EB4Full; h ^= (h >> 29); h += k.c; h *= 0x165667B19E3779F9ull;
+        return (size_t)(h ^ (h >> 32));
+    }
+};
+inline uint32_t fbits(float f) {
+    if (f == 0.0f) f = 0.0f; /* -0 and +0 are the same map key for the reference's '<' ordering */
+    uint32_t u; memcpy(&u, &f, 4); return u;
+}
+inline VKey vkey(F3 p) { VKey k; k.a = fbits(p.x); k.b = fbits(p.y); k.c = fbits(p.z); return k; }
+
+/* compute_barycentric_normals (reference stlreader.cpp:62-81): a corner's normal is the
+ * normalised sum, taken in mesh order, of the face normals of all corners at the same
+ * position.  A hash of vertex positions replaces the reference's ordered map; the running
+ * sum visits contributions in the same order as the reference's per-vertex list. */
+void vertex_normals(Mesh& m) {
+    std::unordered_map<VKey, int32_t, VKeyHash> ids;
+    ids.reserve((size_t)m.n * 2);
+    std::vector<int32_t> corner((size_t)m.n * 3);
+    std::vector<F3> sum;
+    for (int64_t i = 0; i < m.n; i++) {
+        const F3 c[3] = {m.p0[i], m.p1[i], m.p2[i]};
+        for (int k = 0; k < 3; k++) {
+            auto it = ids.find(vkey(c[k]));
+            int32_t id;
+            if (it == ids.end()) { id = (int32_t)sum.size(); ids.emplace(vkey(c[k]), id); sum.push_back(f3(0, 0, 0)); }
+            else id = it->second;
+            corner[3 * i + k] = id;
+            sum[id] = add(sum[id], m.normal[i]);
+        }
+    }
+    for (auto& s : sum) s = unit(s);
+    m.vn0.resize(m.n); m.vn1.resize(m.n); m.vn2.resize(m.n);
+    for (int64_t i = 0; i < m.n; i++) {
+        m.vn0[i] = sum[corner[3 * i]]; m.vn1[i] = sum[corner[3 * i + 1]]; m.vn2[i] = sum[corner[3 * i + 2]];
+    }
+}
+
+/* read_stl (reference stlreader.cpp:10-43): binary only, 80-byte header ignored, file
+ * normals ignored, attribute byte count must be zero. */
+bool load_stl(const char* path, std::vector<float>& soup) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return false;
+    char header[80];
+    uint32_t count = 0;
+    bool ok = fread(header, 80, 1, fp) == 1 && fread(&count, 4, 1, fp) == 1;
+    if (ok) {
+        std::vector<unsigned char> buf((size_t)count * 50);
+        ok = count == 0 || fread(buf.data(), 50, count, fp) == count;
+        if (ok) {
+            soup.resize((size_t)count * 9);
+            for (uint32_t i = 0; i < count && ok; i++) {
+                memcpy(&soup[(size_t)i * 9], &buf[(size_t)i * 50 + 12], 36);
+                uint16_t attr; memcpy(&attr, &buf[(size_t)i * 50 + 48], 2);
+                if (attr != 0) ok = false;
+            }
+        }
+    }
+    fclose(fp);
+    return ok;
+}
+
+/* ------------------------------------------------------------------ builder */
+
+const int LEAF_THRESHOLD = 8; /* reference kdtree.cpp:12 */
+const int MAXIMUM_DEPTH = 19; /* reference kdtree.cpp:13 */
+
+struct BNode {
+    int depth = 0, axis = 0;
+    float split = 0;
+    float bmin[3], bmax[3];
+    bool leaf = false;
+    int64_t begin = 0, count = 0; /* segment of the six index arrays */
+    BNode* lo = nullptr;
+    BNode* hi = nullptr;
+    ~BNode() { delete lo; delete hi; }
+};
+
+struct Builder {
+    const Mesh* m;
+    std::vector<int32_t> lists[2][3]; /* [0]=by minimum, [1]=by maximum; per axis */
+    std::vector<uint8_t> low_side;    /* per triangle, scratch of the node that owns it */
+    int spawn_depth = 0;
+    int wide_threads = 1;
+
+    const float* coord(int mm, int axis) const { return mm == 0 ? m->bmin[axis].data() : m->bmax[axis].data(); }
+
+    /* Best split on one axis; candidates in ascending order, strict '<' keeps the first
+     * (reference kdtree.cpp:104-145). */
+    void best_on_axis(int axis, int64_t begin, int64_t count, int inc, float& score_io, float& split_io, int& axis_io) const {
+        const int32_t* ours = lists[0][0].data() + begin;
+        const float* mx = m->bmax[axis].data();
+        for (int64_t tt = 0; tt < count; tt += inc) {
+            float sample = mx[ours[tt]];
+            int side[2];
+            for (int mm = 0; mm < 2; mm++) {
+                const int32_t* l = lists[mm][axis].data() + begin;
+                const float* c = coord(mm, axis);
+                uint64_t low = 0, high = (uint64_t)count;
+                while (low + 1 < high) {
+                    uint64_t mid = (low + high) / 2;
+                    if (c[l[mid]] <= sample) low = mid; else high = mid;
+                }
+                side[mm] = mm == 0 ? (int)(low + 1) : (int)((uint64_t)count - high);
+            }
+            float score = sel_max((float)side[0], (float)side[1]);
+            if (score < score_io) { score_io = score; split_io = sample; axis_io = axis; }
+        }
+    }
+
+    /* Stable partition of one list segment: low-side triangles first, order kept on both sides. */
+    int64_t partition(int mm, int axis, int64_t begin, int64_t count) {
+        int32_t* a = lists[mm][axis].data() + begin;
+        std::vector<int32_t> high;
+        high.reserve((size_t)count / 2 + 8);
+        int64_t nl = 0;
+        for (int64_t i = 0; i < count; i++) {
+            int32_t t = a[i];
+            if (low_side[t]) a[nl++] = t; else high.push_back(t);
+        }
+        if (!high.empty()) memcpy(a + nl, high.data(), high.size() * sizeof(int32_t));
+        return nl;
+    }
+
+    BNode* build(int depth, int64_t begin, int64_t count) {
+        BNode* n = new BNode();
+        n->depth = depth; n->begin = begin; n->count = count;
+        const int32_t* ours = lists[0][0].data() + begin;
+        const float inf = (float)1e100; /* FLOAT_INF narrowed, reference utils.h:10 */
+        for (int a = 0; a < 3; a++) {
+            float lo = inf, hi = -inf;
+            const float* mn = m->bmin[a].data();
+            const float* mx = m->bmax[a].data();
+            for (int64_t i = 0; i < count; i++) { lo = sel_min(lo, mn[ours[i]]); hi = sel_max(hi, mx[ours[i]]); }
+            n->bmin[a] = lo; n->bmax[a] = hi;
+        }
+        if (count <= LEAF_THRESHOLD || depth >= MAXIMUM_DEPTH) { n->leaf = true; return n; }
+        int inc = 8;                 /* reference kdtree.cpp:92-98 */
+        if (count < 10000) inc = 4;
+        if (count < 1000) inc = 2;
+        if (count < 100) inc = 1;
+        float best_score = inf, best_split = 0.0f;
+        int best_axis = -1;
+        bool wide = wide_threads > 1 && count >= 200000;
+        if (wide) {
+            float sc[3] = {inf, inf, inf}, sp[3] = {0, 0, 0};
+            int ax[3] = {-1, -1, -1};
+            std::thread th[3];
+            for (int a = 0; a < 3; a++) th[a] = std::thread([&, a]() { best_on_axis(a, begin, count, inc, sc[a], sp[a], ax[a]); });
+            for (int a = 0; a < 3; a++) th[a].join();
+            for (int a = 0; a < 3; a++) if (sc[a] < best_score) { best_score = sc[a]; best_split = sp[a]; best_axis = ax[a]; }
+        } else {
+            for (int a = 0; a < 3; a++) best_on_axis(a, begin, count, inc, best_score, best_split, best_axis);
+        }
+        n->axis = best_axis; n->split = best_split;
+        /* low iff the triangle's minimum on the split axis is <= the split height; every other
+         * triangle goes high (reference kdtree.cpp:172-183). */
+        const float* mn = m->bmin[best_axis].data();
+        int64_t lo_n = 0;
+        for (int64_t i = 0; i < count; i++) { bool b = mn[ours[i]] <= best_split; low_side[ours[i]] = b; lo_n += b; }
+        if (lo_n == count || lo_n == 0) { /* reference kdtree.cpp:206-208 */
+            n->leaf = true; n->axis = 0; n->split = 0;
+            return n;
+        }
+        if (wide) {
+            std::thread th[6];
+            for (int k = 0; k < 6; k++) th[k] = std::thread([&, k]() { partition(k / 3, k % 3, begin, count); });
+            for (int k = 0; k < 6; k++) th[k].join();
+        } else {
+            for (int k = 0; k < 6; k++) partition(k / 3, k % 3, begin, count);
+        }
+        if (depth < spawn_depth) {
+            std::thread th([&]() { n->lo = build(depth + 1, begin, lo_n); });
+            n->hi = build(depth + 1, begin + lo_n, count - lo_n);
+            th.join();
+        } else {
+            n->lo = build(depth + 1, begin, lo_n);
+            n->hi = build(depth + 1, begin + lo_n, count - lo_n);
+        }
+        return n;
+    }
+
+    /* Six index lists sorted once with std::sort and a strict '<' on one box coordinate
+     * (reference kdtree.cpp:479-494, comparator :404-409).  Ties end up in whatever order
+     * libstdc++'s introsort leaves for the identity input sequence, so the same call on the
+     * same sequence is the only way to reproduce the reference's leaf order. */
+    BNode* run(int threads) {
+        int64_t n = m->n;
+        std::vector<std::thread> pool;
+        for (int k = 0; k < 6; k++) {
+            auto job = [this, k, n]() {
+                int mm = k / 3, axis = k % 3;
+                std::vector<int32_t>& l = lists[mm][axis];
+                l.resize((size_t)n);
+                for (int64_t i = 0; i < n; i++) l[i] = (int32_t)i;
+                const float* c = coord(mm, axis);
+                std::sort(l.begin(), l.end(), [c](const int& a, const int& b) { return c[a] < c[b]; });
+            };
+            if (threads > 1) pool.emplace_back(job); else job();
+        }
+        for (auto& t : pool) t.join();
+        low_side.assign((size_t)n, 0);
+        spawn_depth = 0;
+        while ((1 << spawn_depth) < threads) spawn_depth++;
+        wide_threads = threads;
+        return build(0, 0, n);
+    }
+};
+
+struct Flat {
+    std::vector<pt_flat_node> nodes;
+    std::vector<pt_tri_isect> tris;
+    std::vector<pt_tri_shade> shade;
+    pt_flat_scene desc;
+};
+
+uint32_t leaf_ref(const BNode* n) {
+    uint32_t cnt = n->count <= 31 ? (uint32_t)n->count : 0u;
+    return PT_REF_LEAF | (cnt << PT_REF_COUNT_SHIFT) | (uint32_t)n->begin;
+}
+
+/* Interior nodes in depth-first pre-order (low subtree directly after its parent). */
+uint32_t flatten_rec(const BNode* n, Flat& f, uint32_t& max_depth) {
+    if (n->leaf) return leaf_ref(n);
+    uint32_t me = (uint32_t)f.nodes.size();
+    f.nodes.push_back(pt_flat_node());
+    if ((uint32_t)n->depth + 1 > max_depth) max_depth = (uint32_t)n->depth + 1;
+    uint32_t lo = flatten_rec(n->lo, f, max_depth);
+    uint32_t hi = flatten_rec(n->hi, f, max_depth);
+    pt_flat_node& fn = f.nodes[me];
+    for (int a = 0; a < 3; a++) {
+        fn.lo_min[a] = n->lo->bmin[a]; fn.lo_max[a] = n->lo->bmax[a];
+        fn.hi_min[a] = n->hi->bmin[a]; fn.hi_max[a] = n->hi->bmax[a];
+    }
+    fn.lo_ref = lo; fn.hi_ref = hi; fn.axis = (uint32_t)n->axis; fn.pad = 0;
+    return me;
+}
+
+void mark_leaf_counts(const BNode* n, Flat& f) {
+    if (n->leaf) { if (n->count > 0) f.tris[(size_t)n->begin].leaf_count = (uint32_t)n->count; return; }
+    mark_leaf_counts(n->lo, f);
+    mark_leaf_counts(n->hi, f);
+}
+
+/* Triangle::project_point_to_given_altitude's plane parameter (reference utils.cpp:167). */
+inline float plane_of(F3 nrm, F3 a, F3 b, F3 c) {
+    float s = (dot3(nrm, a) + dot3(nrm, b)) + dot3(nrm, c);
+    return (float)((double)s / 3.0);
+}
+
+void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm, Flat& f) {
+    uint32_t max_depth = 0;
+    f.nodes.clear();
+    uint32_t root_ref = flatten_rec(root, f, max_depth);
+    f.tris.resize((size_t)m.n);
+    f.shade.resize((size_t)m.n);
+    for (int64_t k = 0; k < m.n; k++) {
+        int32_t i = perm[(size_t)k];
+        pt_tri_isect& ti = f.tris[(size_t)k];
+        F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
+        ti.p0[0] = m.p0[i].x; ti.p0[1] = m.p0[i].y; ti.p0[2] = m.p0[i].z;
+        ti.e1[0] = e1.x; ti.e1[1] = e1.y; ti.e1[2] = e1.z;
+        ti.e2[0] = e2.x; ti.e2[1] = e2.y; ti.e2[2] = e2.z;
+        ti.mesh_index = (uint32_t)i; ti.leaf_count = 0; ti.pad = 0;
+        pt_tri_shade& ts = f.shade[(size_t)k];
+        memset(&ts, 0, sizeof(ts));
+        ts.normal[0] = m.normal[i].x; ts.normal[1] = m.normal[i].y; ts.normal[2] = m.normal[i].z;
+        ts.plane = plane_of(m.normal[i], m.p0[i], m.p1[i], m.p2[i]);
+        F3 un = sub(m.vn1[i], m.vn0[i]), vn = sub(m.vn2[i], m.vn0[i]); /* Triangle::set_normals, utils.cpp:131-135 */
+        ts.base_n[0] = m.vn0[i].x; ts.base_n[1] = m.vn0[i].y; ts.base_n[2] = m.vn0[i].z;
+        ts.u_n[0] = un.x; ts.u_n[1] = un.y; ts.u_n[2] = un.z;
+        ts.v_n[0] = vn.x; ts.v_n[1] = vn.y; ts.v_n[2] = vn.z;
+    }
+    mark_leaf_counts(root, f);
+    memset(&f.desc, 0, sizeof(f.desc));
+    f.desc.n_nodes = f.nodes.size();
+    f.desc.n_tris = (uint64_t)m.n;
+    f.desc.nodes = f.nodes.data();
+    f.desc.tris = f.tris.data();
+    f.desc.shade = f.shade.data();
+    f.desc.root_ref = root_ref;
+    f.desc.max_depth = max_depth;
+    for (int a = 0; a < 3; a++) { f.desc.root_min[a] = root->bmin[a]; f.desc.root_max[a] = root->bmax[a]; }
+}
+
+void dump_rec(const BNode* n, const std::vector<int32_t>& perm, std::vector<float>* nodes, std::vector<int32_t>* leaves,
+              int64_t* stats) {
+    int64_t cnt = n->leaf ? n->count : 0;
+    if (stats) {
+        stats[0]++;
+        if (n->leaf) { stats[1]++; stats[4] += cnt; }
+        if (n->depth > stats[2]) stats[2] = n->depth;
+        if (cnt > stats[3]) stats[3] = cnt;
+    }
+    if (nodes) {
+        float rec[10] = {n->leaf ? 1.0f : 0.0f, (float)n->axis, n->split, n->bmin[0], n->bmin[1], n->bmin[2],
+                         n->bmax[0], n->bmax[1], n->bmax[2], (float)cnt};
+        nodes->insert(nodes->end(), rec, rec + 10);
+    }
+    if (leaves && n->leaf) leaves->insert(leaves->end(), perm.begin() + n->begin, perm.begin() + n->begin + n->count);
+    if (!n->leaf) { dump_rec(n->lo, perm, nodes, leaves, stats); dump_rec(n->hi, perm, nodes, leaves, stats); }
+}
+
+} // namespace
+
+struct pth_scene {
+    Mesh mesh;
+    BNode* root = nullptr;
+    std::vector<int32_t> perm;
+    Flat flat;
+    double t_normals = 0, t_build = 0, t_flatten = 0;
+    ~pth_scene() { delete root; }
+};
+
+static pth_scene* finish(pth_scene* s, int threads) {
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 8; }
+    if (s->mesh.n >= (int64_t)PT_MAX_TRIANGLES) { delete s; return nullptr; }
+    double t0 = now_s();
+    vertex_normals(s->mesh);
+    double t1 = now_s();
+    Builder b;
+    b.m = &s->mesh;
+    s->root = b.run(threads);
+    s->perm.swap(b.lists[0][0]);
+    double t2 = now_s();
+    flatten(s->mesh, s->root, s->perm, s->flat);
+    double t3 = now_s();
+    s->t_normals = t1 - t0; s->t_build = t2 - t1; s->t_flatten = t3 - t2;
+    return s;
+}
+
+extern "C" {
+
+pth_scene* pth_scene_from_stl(const char* path, int threads) {
+    std::vector<float> soup;
+    if (!path || !load_stl(path, soup)) return nullptr;
+    pth_scene* s = new pth_scene();
+    mesh_from_soup(s->mesh, soup.data(), (int64_t)(soup.size() / 9));
+    return finish(s, threads);
+}
+
+pth_scene* pth_scene_from_triangles(const float* verts, int64_t n, int threads) {
+    if (n < 0 || (n > 0 && !verts)) return nullptr;
+    pth_scene* s = new pth_scene();
+    mesh_from_soup(s->mesh, verts, n);
+    return finish(s, threads);
+}
+
+void pth_scene_destroy(pth_scene* s) { delete s; }
+
+int64_t pth_num_triangles(const pth_scene* s) { return s->mesh.n; }
+
+const pt_flat_scene* pth_flat_scene(const pth_scene* s) { return &s->flat.desc; }
+
+void pth_timings(const pth_scene* s, double out[3]) { out[0] = s->t_normals; out[1] = s->t_build; out[2] = s->t_flatten; }
+
+void pth_triangle_data(const pth_scene* s, float* out) {
+    const Mesh& m = s->mesh;
+    for (int64_t i = 0; i < m.n; i++) {
+        F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
+        const F3 v[9] = {m.p0[i], m.p1[i], m.p2[i], e1, e2, m.normal[i], m.vn0[i], sub(m.vn1[i], m.vn0[i]), sub(m.vn2[i], m.vn0[i])};
+        float* o = out + 30 * i;
+        for (int k = 0; k < 9; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
+        o[27] = plane_of(m.normal[i], m.p0[i], m.p1[i], m.p2[i]);
+        o[28] = o[29] = 0.0f;
+    }
+}
+
+void pth_tree_stats(const pth_scene* s, int64_t stats[5]) {
+    for (int i = 0; i < 5; i++) stats[i] = 0;
+    dump_rec(s->root, s->perm, nullptr, nullptr, stats);
+}
+
+void pth_tree_dump(const pth_scene* s, float* nodes10, int32_t* leaf_indices) {
+    std::vector<float> nodes;
+    std::vector<int32_t> leaves;
+    dump_rec(s->root, s->perm, &nodes, &leaves, nullptr);
+    memcpy(nodes10, nodes.data(), nodes.size() * sizeof(float));
+    if (!leaves.empty()) memcpy(leaf_indices, leaves.data(), leaves.size() * sizeof(int32_t));
+}
+
+} // extern "C"
