@@ -28,13 +28,15 @@ extern "C" {
 
 /* ---- flattened scene (host side produces it; see pt_host.h) ------------------------- */
 
-/* Child reference: bit 31 set = leaf, bits 30..26 = triangle count (1..31, or 0 when the
- * count is stored in the first triangle's `leaf_count`), bits 25..0 = index of the leaf's
- * first triangle.  Bit 31 clear = index of an interior node. */
+/* Child reference: bit 31 set = leaf, bit 30 = 0 (reserved for the traversal stack),
+ * bits 29..26 = triangle count (1..15, or 0 when the count is stored in the first triangle's
+ * `leaf_count`), bits 25..0 = index of the leaf's first triangle.  Bit 31 clear = index of an
+ * interior node.  0xffffffff is never a valid reference. */
 #define PT_REF_LEAF        0x80000000u
 #define PT_REF_COUNT_SHIFT 26
+#define PT_REF_COUNT_MASK  0xfu
 #define PT_REF_START_MASK  0x03ffffffu
-#define PT_MAX_TRIANGLES   (1u << 26)
+#define PT_MAX_TRIANGLES   ((1u << 26) - 64u)
 #define PT_MAX_TREE_DEPTH  20      /* interior levels above any leaf; reference caps at 19 (kdtree.cpp:13) */
 #define PT_MAX_LIGHTS      16
 

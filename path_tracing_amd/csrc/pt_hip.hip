@@ -1,0 +1,1028 @@
+/*
+ * pt_hip.hip -- MI355X (gfx950) ray-casting library: kernels and the C ABI of include/pt_hip.h.
+ *
+ * Data in HBM
+ *   nodes  : pt_flat_node[n_nodes], 64 B each, one per interior node, both child boxes inside
+ *   tris   : pt_tri_isect[n_tris], 48 B each, leaf order (what the triangle test reads)
+ *   shade  : pt_tri_shade[n_tris], 64 B each, same order (what shading reads after a hit)
+ *   rays / hits / queues : structure-of-arrays, one float or int array per component, so a
+ *            wave's 64 lanes read and write 256 contiguous bytes per component
+ *
+ * Kernels (all HBM/latency bound; no matrix work anywhere on this path)
+ *   k_trace<CLOSEST>  closest hit, the reference's visit order reproduced exactly
+ *   k_trace<ANYHIT>   light visibility for rays whose light is at least one unit away
+ *   k_generate        camera rays of a batch of tile passes
+ *   k_shade           surface frame, light samples, bounce ray; compacts surviving paths with
+ *                     a wave ballot and one atomic per wave
+ *   k_accumulate      adds the visible light samples to each path in light order
+ *   k_film            adds finished paths to the film in sample order
+ * Trace kernels are persistent: a fixed grid of waves pulls 64-ray chunks from an atomic
+ * counter until the queue is empty; queue lengths live in device memory, so a whole batch of
+ * bounces is enqueued without a host round trip.
+ *
+ * Build: hipcc -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_hip.h"
+#include "shade_core.h"
+#include "traverse_core.h"
+
+using namespace ptc;
+
+/* ------------------------------------------------------------------ errors */
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+/* ------------------------------------------------------------ device views */
+
+struct DScene {
+    const float4* nodes;
+    const float4* tris;
+    const float4* shade;
+    uint32_t root_ref;
+    uint32_t n_tris;
+    RootBox root;
+};
+
+struct RaySoA {
+    const float *ox, *oy, *oz, *dx, *dy, *dz;
+};
+struct RaySoAW {
+    float *ox, *oy, *oz, *dx, *dy, *dz;
+};
+
+#define TRACE_BLOCK 256
+#define STACK_CLOSEST (3 * PT_MAX_TREE_DEPTH)
+#define STACK_ANYHIT (PT_MAX_TREE_DEPTH)
+
+struct GpuMem {
+    const float4* nodes;
+    const float4* tris;
+    __device__ __forceinline__ void load_node(uint32_t i, NodeData& n) const {
+        const float4* p = nodes + (size_t)i * 4;
+        float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        n.lo_min[0] = a.x; n.lo_min[1] = a.y; n.lo_min[2] = a.z;
+        n.lo_max[0] = a.w; n.lo_max[1] = b.x; n.lo_max[2] = b.y;
+        n.hi_min[0] = b.z; n.hi_min[1] = b.w; n.hi_min[2] = c.x;
+        n.hi_max[0] = c.y; n.hi_max[1] = c.z; n.hi_max[2] = c.w;
+        n.lo_ref = __float_as_uint(d.x); n.hi_ref = __float_as_uint(d.y); n.axis = __float_as_uint(d.z);
+    }
+    __device__ __forceinline__ void load_tri(uint32_t k, TriData& t) const {
+        const float4* p = tris + (size_t)k * 3;
+        float4 a = p[0], b = p[1], c = p[2];
+        t.p0x = a.x; t.p0y = a.y; t.p0z = a.z;
+        t.e1x = a.w; t.e1y = b.x; t.e1z = b.y;
+        t.e2x = b.z; t.e2y = b.w; t.e2z = c.x;
+        t.mesh_index = __float_as_uint(c.y); t.leaf_count = __float_as_uint(c.z);
+    }
+};
+
+/* Per-lane stack in LDS, dword-interleaved across the block: entry i of thread t lives at
+ * word i*TRACE_BLOCK + t, so whatever the lanes' depths are, a wave's 64 accesses fall in 64
+ * different words of two bank rows and never conflict. */
+struct LdsStack {
+    uint32_t* base;
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) { base[sp * TRACE_BLOCK] = v; sp++; }
+    __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * TRACE_BLOCK]; }
+};
+
+/* ----------------------------------------------------------------- tracing */
+
+enum TraceMode {
+    TRACE_CLOSEST_MESH = 0, /* outputs mesh index, t, u, v              (pt_raycast_closest) */
+    TRACE_CLOSEST_FLAT = 1, /* outputs leaf-order position, t, u, v     (renderer)           */
+    TRACE_SHADOW_ANY = 2,   /* visibility for dist >= 1; marks others 2 (see k_trace)        */
+    TRACE_SHADOW_EXACT = 3  /* visibility for the rays marked 2: closest hit, v > dist       */
+};
+
+struct TraceArgs {
+    RaySoA rays;
+    const uint32_t* d_count; /* number of rays, in device memory */
+    uint32_t* d_next_chunk;  /* atomic chunk counter, zero at launch */
+    int32_t* out_idx;
+    float *out_t, *out_u, *out_v;
+    const float* dist;       /* shadow modes */
+    uint8_t* vis;            /* shadow modes */
+};
+
+template <int MODE>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
+    constexpr bool ANY = (MODE == TRACE_SHADOW_ANY);
+    constexpr int CAP = ANY ? STACK_ANYHIT : STACK_CLOSEST;
+    __shared__ uint32_t stk[CAP * TRACE_BLOCK];
+    const uint32_t n = *a.d_count;
+    const uint32_t lane = threadIdx.x & 63u;
+    GpuMem mem;
+    mem.nodes = sc.nodes; mem.tris = sc.tris;
+    while (true) {
+        /* one atomic per wave: the next 64 consecutive rays */
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(a.d_next_chunk, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        uint64_t first = (uint64_t)chunk * 64u;
+        if (first >= n) break;
+        uint32_t i = (uint32_t)first + lane;
+        if (i < n) {
+            bool skip = false;
+            float dist = 0.0f;
+            if (MODE == TRACE_SHADOW_ANY) {
+                dist = a.dist[i];
+                /* Every hit has v <= 1, so with dist >= 1 the reference's test `v > dist` fails for
+                 * any hit and the answer is hit/no-hit.  Nearer lights need the closest hit's v. */
+                if (!(dist >= 1.0f)) { a.vis[i] = 2; skip = true; }
+            }
+            if (MODE == TRACE_SHADOW_EXACT) {
+                if (a.vis[i] != 2) skip = true; else dist = a.dist[i];
+            }
+            if (!skip) {
+                Ray9 r;
+                r.ox = a.rays.ox[i]; r.oy = a.rays.oy[i]; r.oz = a.rays.oz[i];
+                r.dx = a.rays.dx[i]; r.dy = a.rays.dy[i]; r.dz = a.rays.dz[i];
+                ray_set_recip(r);
+                LdsStack st;
+                st.base = stk + threadIdx.x; st.sp = 0;
+                Hit h;
+                bool found = trace_lane<ANY>(mem, sc.root_ref, sc.root, r, st, h);
+                if (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) {
+                    a.out_idx[i] = found ? (int32_t)(MODE == TRACE_CLOSEST_MESH ? h.mesh : h.tri) : -1;
+                    a.out_t[i] = found ? h.t : 0.0f;
+                    a.out_u[i] = found ? h.u : 0.0f;
+                    a.out_v[i] = found ? h.v : 0.0f;
+                } else if (MODE == TRACE_SHADOW_ANY) {
+                    a.vis[i] = found ? 0 : 1;
+                } else {
+                    a.vis[i] = (!found || h.v > dist) ? 1 : 0;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------- wavefront renderer */
+
+struct DLight { V3f pos, color; };
+
+/* One entry of a batch: n_samples consecutive samples of one rectangle.  Paths of the entry
+ * are numbered path0 + s*padded + q, q walking the rectangle in 8x8 pixel blocks so that the
+ * 64 lanes of a wave start out as a compact screen tile. */
+struct SubPass {
+    int32_t x, y, w, h;
+    uint32_t first_sample, n_samples;
+    uint32_t blocks_x, padded; /* ceil(w/8); 64*ceil(w/8)*ceil(h/8) */
+    uint32_t path0;
+    uint32_t group_first;      /* first entry in the batch with the same rectangle */
+};
+
+struct RenderBuffers {
+    /* two ray queues (current / next) */
+    RaySoAW q[2];
+    uint32_t* qpath[2];
+    /* hits of the current queue */
+    int32_t* hit_tri;
+    float *hit_t, *hit_u, *hit_v;
+    /* per path */
+    uint32_t *pixel, *sample;
+    float *rad_r, *rad_g, *rad_b, *thr;
+    /* per light sample of the current depth: slot*n_lights + l */
+    RaySoAW sh;
+    float *sh_dist, *sh_wr, *sh_wg, *sh_wb;
+    uint8_t* sh_vis;
+    /* counters: [0..11] queue length per depth, [12..23] trace chunk counters (closest),
+     * [24..35] shadow-ray count per depth, [36..47] chunk counters (shadow any),
+     * [48..59] chunk counters (shadow exact), [60] camera samples */
+    uint32_t* cnt;
+};
+#define CNT_QUEUE 0
+#define CNT_CHUNK_CLOSEST 12
+#define CNT_SHADOW 24
+#define CNT_CHUNK_ANY 36
+#define CNT_CHUNK_EXACT 48
+#define CNT_SAMPLES 60
+#define CNT_WORDS 64
+
+__device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_sp, uint32_t p) {
+    uint32_t lo = 0, hi = n_sp;
+    while (lo + 1 < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sp[mid].path0 <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_generate(CamParams cam, const SubPass* sp, uint32_t n_sp, uint32_t n_paths,
+                                                   uint64_t seed, RenderBuffers b) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false;
+    int px = 0, py = 0;
+    uint32_t sample = 0;
+    if (p < n_paths) {
+        const SubPass s = sp[find_subpass(sp, n_sp, p)];
+        uint32_t local = p - s.path0;
+        uint32_t si = local / s.padded, q = local - si * s.padded;
+        uint32_t blk = q >> 6, lx = q & 7u, ly = (q >> 3) & 7u;
+        int bx = (int)(blk % s.blocks_x), by = (int)(blk / s.blocks_x);
+        int rx = bx * 8 + (int)lx, ry = by * 8 + (int)ly;
+        valid = rx < s.w && ry < s.h;
+        px = s.x + rx; py = s.y + ry;
+        sample = s.first_sample + si;
+    }
+    uint32_t pixel = valid ? (uint32_t)(py * cam.width + px) : 0xffffffffu;
+    if (p < n_paths) {
+        b.pixel[p] = pixel; b.sample[p] = sample;
+        b.rad_r[p] = 0.0f; b.rad_g[p] = 0.0f; b.rad_b[p] = 0.0f; b.thr[p] = 1.0f;
+    }
+    /* compact valid paths into queue 0: one atomic per wave */
+    uint64_t mask = __ballot(valid);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0 && mask) {
+        uint32_t c = (uint32_t)__popcll(mask);
+        base = atomicAdd(&b.cnt[CNT_QUEUE + 0], c);
+        atomicAdd(&b.cnt[CNT_SAMPLES], c);
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (valid) {
+        uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        V3f o, d;
+        camera_ray_jittered(cam, px, py, sample, seed, o, d);
+        b.q[0].ox[slot] = o.x; b.q[0].oy[slot] = o.y; b.q[0].oz[slot] = o.z;
+        b.q[0].dx[slot] = d.x; b.q[0].dy[slot] = d.y; b.q[0].dz[slot] = d.z;
+        b.qpath[0][slot] = p;
+    }
+}
+
+/* Camera rays only, row-major over a rectangle (parity checks of the generate step). */
+__global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int y0, int w, int h, int jittered,
+                                                      uint32_t sample, uint64_t seed, RaySoAW out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (uint32_t)(w * h)) return;
+    int x = x0 + (int)(k % (uint32_t)w), y = y0 + (int)(k / (uint32_t)w);
+    V3f o, d;
+    if (jittered) camera_ray_jittered(cam, x, y, sample, seed, o, d);
+    else camera_ray_plain(cam, x, y, o, d);
+    out.ox[k] = o.x; out.oy[k] = o.y; out.oz[k] = o.z;
+    out.dx[k] = d.x; out.dy[k] = d.y; out.dz[k] = d.z;
+}
+
+/* Hit branch of cast_ray for every ray of the current queue (cur = depth & 1). */
+__global__ __launch_bounds__(256) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
+                                                uint32_t depth, int last_depth, uint64_t seed, RenderBuffers b) {
+    const uint32_t n = b.cnt[CNT_QUEUE + depth];
+    const int cur = depth & 1, nxt = cur ^ 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base_i = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); base_i < n; base_i += gridDim.x * blockDim.x) {
+        uint32_t i = base_i + lane;
+        bool hit = false;
+        uint32_t path = 0;
+        int32_t tri = -1;
+        if (i < n) {
+            path = b.qpath[cur][i];
+            tri = b.hit_tri[i];
+            hit = tri >= 0;
+            if (!hit) { /* sky, reference integrator.cpp:153 */
+                float thr = b.thr[path];
+                if (cam.sky.x != 0.0f || cam.sky.y != 0.0f || cam.sky.z != 0.0f) {
+                    b.rad_r[path] += thr * cam.sky.x; b.rad_g[path] += thr * cam.sky.y; b.rad_b[path] += thr * cam.sky.z;
+                }
+            }
+        }
+        uint64_t mask = __ballot(hit);
+        uint32_t wbase = 0;
+        if (lane == 0 && mask) {
+            uint32_t c = (uint32_t)__popcll(mask);
+            wbase = atomicAdd(&b.cnt[CNT_QUEUE + depth + 1], c);
+            atomicAdd(&b.cnt[CNT_SHADOW + depth], c * n_lights);
+        }
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (hit) {
+            uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const float4* sp = sc.shade + (size_t)tri * 4;
+            float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            ShadeTri st;
+            st.normal = v3(s0.x, s0.y, s0.z); st.plane = s0.w;
+            st.base_n = v3(s1.x, s1.y, s1.z); st.u_n = v3(s2.x, s2.y, s2.z); st.v_n = v3(s3.x, s3.y, s3.z);
+            V3f o = v3(b.q[cur].ox[i], b.q[cur].oy[i], b.q[cur].oz[i]);
+            V3f d = v3(b.q[cur].dx[i], b.q[cur].dy[i], b.q[cur].dz[i]);
+            SurfaceFrame f = surface_frame(o, d, b.hit_t[i], b.hit_u[i], b.hit_v[i], st);
+            float thr = b.thr[path];
+            uint32_t pixel = b.pixel[path], sample = b.sample[path];
+            for (uint32_t l = 0; l < n_lights; l++) {
+                LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
+                uint32_t j = slot * n_lights + l;
+                b.sh.ox[j] = f.hit.x; b.sh.oy[j] = f.hit.y; b.sh.oz[j] = f.hit.z;
+                b.sh.dx[j] = ls.dir.x; b.sh.dy[j] = ls.dir.y; b.sh.dz[j] = ls.dir.z;
+                b.sh_dist[j] = ls.dist;
+                b.sh_wr[j] = thr * ls.weight.x; b.sh_wg[j] = thr * ls.weight.y; b.sh_wb[j] = thr * ls.weight.z;
+            }
+            b.qpath[nxt][slot] = path;
+            if (!last_depth) {
+                V3f bo, bd;
+                bounce_ray(f, bo, bd);
+                b.q[nxt].ox[slot] = bo.x; b.q[nxt].oy[slot] = bo.y; b.q[nxt].oz[slot] = bo.z;
+                b.q[nxt].dx[slot] = bd.x; b.q[nxt].dy[slot] = bd.y; b.q[nxt].dz[slot] = bd.z;
+                b.thr[path] = 0.8f * thr; /* reference integrator.cpp:107 */
+            }
+        }
+    }
+}
+
+/* Adds the visible light samples of depth `depth` to their paths, lights in order. */
+__global__ __launch_bounds__(256) void k_accumulate(uint32_t n_lights, uint32_t depth, RenderBuffers b) {
+    const uint32_t n = b.cnt[CNT_QUEUE + depth + 1];
+    const int nxt = (depth & 1) ^ 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t path = b.qpath[nxt][i];
+        float r = b.rad_r[path], g = b.rad_g[path], bl = b.rad_b[path];
+        for (uint32_t l = 0; l < n_lights; l++) {
+            uint32_t j = i * n_lights + l;
+            if (b.sh_vis[j] == 1) { r += b.sh_wr[j]; g += b.sh_wg[j]; bl += b.sh_wb[j]; }
+        }
+        b.rad_r[path] = r; b.rad_g[path] = g; b.rad_b[path] = bl;
+    }
+}
+
+/* Adds finished paths to the film: one thread per pixel of each rectangle group, walking the
+ * group's entries and their samples in order, so sums do not depend on scheduling. */
+__global__ __launch_bounds__(256) void k_film(const SubPass* sp, uint32_t n_sp, const uint32_t* group_entry,
+                                               const uint32_t* group_off, uint32_t n_groups, uint32_t total,
+                                               int width, float4* film, RenderBuffers b) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    /* group g owns threads [group_off[g], group_off[g+1]) */
+    uint32_t lo = 0, hi = n_groups;
+    while (lo + 1 < hi) { uint32_t mid = (lo + hi) >> 1; if (group_off[mid] <= k) lo = mid; else hi = mid; }
+    uint32_t first = group_entry[lo];
+    const SubPass s0 = sp[first];
+    uint32_t q = k - group_off[lo];
+    uint32_t blk = q >> 6, lx = q & 7u, ly = (q >> 3) & 7u;
+    int rx = (int)(blk % s0.blocks_x) * 8 + (int)lx, ry = (int)(blk / s0.blocks_x) * 8 + (int)ly;
+    if (rx >= s0.w || ry >= s0.h) return;
+    size_t pix = (size_t)(s0.y + ry) * (size_t)width + (size_t)(s0.x + rx);
+    float4 acc = film[pix];
+    for (uint32_t e = first; e < n_sp; e++) {
+        if (sp[e].group_first != first) continue;
+        const SubPass s = sp[e];
+        for (uint32_t si = 0; si < s.n_samples; si++) {
+            uint32_t p = s.path0 + si * s.padded + q;
+            acc.x += b.rad_r[p]; acc.y += b.rad_g[p]; acc.z += b.rad_b[p];
+            acc.w += 1.0f;
+        }
+    }
+    film[pix] = acc;
+}
+
+__global__ void k_film_split(const float4* film, size_t n, float* rgb, int32_t* passes) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = film[i];
+    rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z;
+    passes[i] = (int32_t)v.w;
+}
+
+/* --------------------------------------------------------------- host side */
+
+struct TimedLaunch { int cls; hipEvent_t a, b; };
+
+struct pt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    DScene d{};
+    void* d_nodes = nullptr;
+    void* d_tris = nullptr;
+    void* d_shade = nullptr;
+    uint64_t n_tris = 0;
+    uint32_t* d_small = nullptr; /* [0] ray count, [1..3] chunk counters for the raycast entry points */
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> free_events;
+    double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
+    uint64_t launches[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
+    bool timing = true;
+};
+
+static int set_device(const pt_scene* s) {
+    HIP_TRY(hipSetDevice(s->device));
+    return PT_OK;
+}
+
+static hipEvent_t get_event(pt_scene* s) {
+    if (!s->free_events.empty()) { hipEvent_t e = s->free_events.back(); s->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+static int resolve_timing(pt_scene* s) {
+    if (s->pending.empty()) return PT_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (auto& t : s->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { s->ms[t.cls] += ms; s->launches[t.cls]++; }
+        s->free_events.push_back(t.a);
+        s->free_events.push_back(t.b);
+    }
+    s->pending.clear();
+    return PT_OK;
+}
+
+struct ScopedTimer {
+    pt_scene* s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(pt_scene* s_, int cls_) : s(s_), cls(cls_) {
+        if (!s->timing) return;
+        a = get_event(s); b = get_event(s);
+        if (a && b) (void)hipEventRecord(a, s->stream);
+    }
+    ~ScopedTimer() {
+        if (!s->timing || !a || !b) return;
+        (void)hipEventRecord(b, s->stream);
+        s->pending.push_back({cls, a, b});
+    }
+};
+
+/* Walks the flattened tree once on the host so that no kernel ever follows a bad reference. */
+static int validate_flat(const pt_flat_scene* f) {
+    if (f->n_tris >= PT_MAX_TRIANGLES) return fail(PT_ERR_LIMIT, "too many triangles (limit 2^26 - 64)");
+    if (f->n_tris == 0) return PT_OK;
+    if (!f->tris || !f->shade) return fail(PT_ERR_INVALID, "null triangle arrays");
+    if (f->n_nodes > 0 && !f->nodes) return fail(PT_ERR_INVALID, "null node array");
+    if (f->n_nodes >= (1u << 26)) return fail(PT_ERR_LIMIT, "too many nodes");
+    struct Item { uint32_t ref; uint32_t depth; };
+    std::vector<Item> stack;
+    std::vector<uint8_t> seen((size_t)f->n_nodes, 0);
+    stack.push_back({f->root_ref, 0});
+    uint64_t tri_total = 0;
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        if (it.ref == 0xffffffffu || (it.ref & 0x40000000u)) return fail(PT_ERR_INVALID, "malformed child reference");
+        if (it.ref & PT_REF_LEAF) {
+            uint32_t start = it.ref & PT_REF_START_MASK;
+            uint32_t count = (it.ref >> PT_REF_COUNT_SHIFT) & PT_REF_COUNT_MASK;
+            if (start >= f->n_tris) return fail(PT_ERR_INVALID, "leaf start outside the triangle array");
+            if (count == 0) count = f->tris[start].leaf_count;
+            if (count == 0 || (uint64_t)start + count > f->n_tris) return fail(PT_ERR_INVALID, "leaf range outside the triangle array");
+            tri_total += count;
+            continue;
+        }
+        if (it.ref >= f->n_nodes) return fail(PT_ERR_INVALID, "node reference out of range");
+        if (seen[it.ref]) return fail(PT_ERR_INVALID, "node referenced twice (not a tree)");
+        seen[it.ref] = 1;
+        if (it.depth + 1 > PT_MAX_TREE_DEPTH) return fail(PT_ERR_LIMIT, "tree deeper than PT_MAX_TREE_DEPTH");
+        const pt_flat_node& n = f->nodes[it.ref];
+        if (n.axis > 2) return fail(PT_ERR_INVALID, "split axis out of range");
+        stack.push_back({n.lo_ref, it.depth + 1});
+        stack.push_back({n.hi_ref, it.depth + 1});
+    }
+    if (tri_total > f->n_tris) return fail(PT_ERR_INVALID, "leaves cover more triangles than the array holds");
+    return PT_OK;
+}
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+
+const char* pt_build_info(void) { return "pt_hip 0.1 (gfx950, strict fp32, persistent-wave trace kernels)"; }
+
+int pt_device_count(int* n) {
+    if (!n) return fail(PT_ERR_INVALID, "null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(PT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = c;
+    return PT_OK;
+}
+
+int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
+    if (!flat || !out) return fail(PT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc = validate_flat(flat);
+    if (rc != PT_OK) return rc;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= count) return fail(PT_ERR_INVALID, "device index out of range");
+    pt_scene* s = new pt_scene();
+    s->device = device;
+    auto cleanup = [&](int code) { pt_scene_destroy(s); return code; };
+    if (hipSetDevice(device) != hipSuccess) return cleanup(fail(PT_ERR_DEVICE, "hipSetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(PT_ERR_DEVICE, "hipStreamCreate failed"));
+    s->n_tris = flat->n_tris;
+    size_t nb = std::max<size_t>(flat->n_nodes, 1) * sizeof(pt_flat_node);
+    size_t tb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_isect);
+    size_t sb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_shade);
+    if (hipMalloc(&s->d_nodes, nb) != hipSuccess || hipMalloc(&s->d_tris, tb) != hipSuccess ||
+        hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, 16 * sizeof(uint32_t)) != hipSuccess)
+        return cleanup(fail(PT_ERR_DEVICE, "hipMalloc failed for the scene arrays"));
+    bool ok = true;
+    if (flat->n_nodes) ok = ok && hipMemcpy(s->d_nodes, flat->nodes, flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
+    if (flat->n_tris) {
+        ok = ok && hipMemcpy(s->d_tris, flat->tris, flat->n_tris * sizeof(pt_tri_isect), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(s->d_shade, flat->shade, flat->n_tris * sizeof(pt_tri_shade), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) return cleanup(fail(PT_ERR_DEVICE, "hipMemcpy failed for the scene arrays"));
+    s->d.nodes = (const float4*)s->d_nodes;
+    s->d.tris = (const float4*)s->d_tris;
+    s->d.shade = (const float4*)s->d_shade;
+    s->d.root_ref = flat->root_ref;
+    s->d.n_tris = (uint32_t)flat->n_tris;
+    s->d.root.mnx = flat->root_min[0]; s->d.root.mny = flat->root_min[1]; s->d.root.mnz = flat->root_min[2];
+    s->d.root.mxx = flat->root_max[0]; s->d.root.mxy = flat->root_max[1]; s->d.root.mxz = flat->root_max[2];
+    *out = s;
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto& t : s->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : s->free_events) (void)hipEventDestroy(e);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_shade) (void)hipFree(s->d_shade);
+    if (s->d_small) (void)hipFree(s->d_small);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int pt_scene_sync(pt_scene* s) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    int rc = set_device(s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+int pt_scene_kernel_time(pt_scene* s, int cls, int reset, double* ms, uint64_t* launches) {
+    if (!s || cls < 0 || cls >= PT_KERNEL_CLASSES) return fail(PT_ERR_INVALID, "bad argument");
+    int rc = set_device(s);
+    if (rc) return rc;
+    rc = resolve_timing(s);
+    if (rc) return rc;
+    if (ms) *ms = s->ms[cls];
+    if (launches) *launches = s->launches[cls];
+    if (reset) { s->ms[cls] = 0; s->launches[cls] = 0; }
+    return PT_OK;
+}
+
+} // extern "C"
+
+/* Grid of a persistent trace launch: as many blocks as stay resident (LDS-limited). */
+static int trace_grid(const pt_scene* s, bool anyhit) {
+    int per_cu = anyhit ? 6 : 2;
+    return s->num_cus * per_cu;
+}
+
+template <int MODE>
+static int launch_trace(pt_scene* s, const TraceArgs& a) {
+    if (s->pending.size() > 8192) { int rc = resolve_timing(s); if (rc) return rc; }
+    ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW);
+    hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY)), dim3(TRACE_BLOCK), 0, s->stream, s->d, a);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+static int fill_miss_closest(pt_scene* s, uint64_t n, int32_t* d_idx, float* d_t, float* d_u, float* d_v) {
+    HIP_TRY(hipMemsetAsync(d_idx, 0xff, n * 4, s->stream));
+    HIP_TRY(hipMemsetAsync(d_t, 0, n * 4, s->stream));
+    HIP_TRY(hipMemsetAsync(d_u, 0, n * 4, s->stream));
+    HIP_TRY(hipMemsetAsync(d_v, 0, n * 4, s->stream));
+    return PT_OK;
+}
+
+extern "C" {
+
+int pt_raycast_closest_dev(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                           const float* dy, const float* dz, int32_t* idx, float* t, float* u, float* v) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !idx || !t || !u || !v) return fail(PT_ERR_INVALID, "null array");
+    if (n >= 0xffffff00ull) return fail(PT_ERR_LIMIT, "more than 2^32-256 rays in one call");
+    int rc = set_device(s);
+    if (rc) return rc;
+    if (s->n_tris == 0) return fill_miss_closest(s, n, idx, t, u, v);
+    uint32_t init[2] = {(uint32_t)n, 0u};
+    HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    TraceArgs a{};
+    a.rays = {ox, oy, oz, dx, dy, dz};
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 1;
+    a.out_idx = idx; a.out_t = t; a.out_u = u; a.out_v = v;
+    return launch_trace<TRACE_CLOSEST_MESH>(s, a);
+}
+
+int pt_raycast_shadow_dev(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                          const float* dy, const float* dz, const float* dist, uint8_t* vis) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !dist || !vis) return fail(PT_ERR_INVALID, "null array");
+    if (n >= 0xffffff00ull) return fail(PT_ERR_LIMIT, "more than 2^32-256 rays in one call");
+    int rc = set_device(s);
+    if (rc) return rc;
+    if (s->n_tris == 0) { HIP_TRY(hipMemsetAsync(vis, 1, n, s->stream)); return PT_OK; }
+    uint32_t init[3] = {(uint32_t)n, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    TraceArgs a{};
+    a.rays = {ox, oy, oz, dx, dy, dz};
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 1;
+    a.dist = dist; a.vis = vis;
+    rc = launch_trace<TRACE_SHADOW_ANY>(s, a);
+    if (rc) return rc;
+    a.d_next_chunk = s->d_small + 2;
+    return launch_trace<TRACE_SHADOW_EXACT>(s, a);
+}
+
+} // extern "C"
+
+/* Host-pointer forms: stage through device buffers that live for the call. */
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 4))); return PT_OK; }
+};
+
+extern "C" {
+
+int pt_raycast_closest(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                       const float* dy, const float* dz, int32_t* idx, float* t, float* u, float* v) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !idx || !t || !u || !v) return fail(PT_ERR_INVALID, "null array");
+    int rc = set_device(s);
+    if (rc) return rc;
+    DevBuf in[6], out[4];
+    const float* src[6] = {ox, oy, oz, dx, dy, dz};
+    for (int k = 0; k < 6; k++) {
+        rc = in[k].alloc(n * 4); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(in[k].p, src[k], n * 4, hipMemcpyHostToDevice, s->stream));
+    }
+    for (int k = 0; k < 4; k++) { rc = out[k].alloc(n * 4); if (rc) return rc; }
+    rc = pt_raycast_closest_dev(s, n, (float*)in[0].p, (float*)in[1].p, (float*)in[2].p, (float*)in[3].p, (float*)in[4].p,
+                                (float*)in[5].p, (int32_t*)out[0].p, (float*)out[1].p, (float*)out[2].p, (float*)out[3].p);
+    if (rc) return rc;
+    void* dst[4] = {idx, t, u, v};
+    for (int k = 0; k < 4; k++) HIP_TRY(hipMemcpyAsync(dst[k], out[k].p, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+int pt_raycast_shadow(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                      const float* dy, const float* dz, const float* dist, uint8_t* vis) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !dist || !vis) return fail(PT_ERR_INVALID, "null array");
+    int rc = set_device(s);
+    if (rc) return rc;
+    DevBuf in[7], out;
+    const float* src[7] = {ox, oy, oz, dx, dy, dz, dist};
+    for (int k = 0; k < 7; k++) {
+        rc = in[k].alloc(n * 4); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(in[k].p, src[k], n * 4, hipMemcpyHostToDevice, s->stream));
+    }
+    rc = out.alloc(n); if (rc) return rc;
+    rc = pt_raycast_shadow_dev(s, n, (float*)in[0].p, (float*)in[1].p, (float*)in[2].p, (float*)in[3].p, (float*)in[4].p,
+                               (float*)in[5].p, (float*)in[6].p, (uint8_t*)out.p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(vis, out.p, n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+} // extern "C"
+
+/* -------------------------------------------------------------------- film */
+
+struct pt_film {
+    pt_scene* scene = nullptr;
+    int width = 0, height = 0;
+    float4* d_film = nullptr;
+    bool owns = false;
+    /* render scratch, allocated on first use */
+    size_t cap_paths = 0;
+    uint32_t cap_lights = 0;
+    std::vector<void*> allocs;
+    RenderBuffers rb{};
+    DLight* d_lights = nullptr;
+    SubPass* d_sub = nullptr;
+    uint32_t* d_groups = nullptr; /* group_entry[cap] then group_off[cap+1] */
+    size_t cap_sub = 0;
+};
+
+static size_t batch_paths_limit() {
+    const char* e = getenv("PT_BATCH_PATHS");
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 22;
+    if (v < 4096) v = 4096;
+    if (v > ((size_t)1 << 27)) v = (size_t)1 << 27;
+    return v;
+}
+
+static void film_free_scratch(pt_film* f) {
+    for (void* p : f->allocs) (void)hipFree(p);
+    f->allocs.clear();
+    f->cap_paths = 0; f->cap_lights = 0; f->cap_sub = 0;
+    f->d_lights = nullptr; f->d_sub = nullptr; f->d_groups = nullptr;
+}
+
+template <class T>
+static int film_alloc(pt_film* f, T** out, size_t count) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    f->allocs.push_back(p);
+    *out = (T*)p;
+    return PT_OK;
+}
+
+static int film_ensure_scratch(pt_film* f, size_t paths, uint32_t n_lights, size_t n_sub) {
+    uint32_t L = std::max<uint32_t>(n_lights, 1);
+    if (paths <= f->cap_paths && L <= f->cap_lights && n_sub <= f->cap_sub) return PT_OK;
+    HIP_TRY(hipStreamSynchronize(f->scene->stream));
+    film_free_scratch(f);
+    size_t P = paths, S = paths * L, G = std::max<size_t>(n_sub, 16);
+    int rc = 0;
+    RenderBuffers& b = f->rb;
+    for (int k = 0; k < 2 && !rc; k++) {
+        float** q[6] = {&b.q[k].ox, &b.q[k].oy, &b.q[k].oz, &b.q[k].dx, &b.q[k].dy, &b.q[k].dz};
+        for (int c = 0; c < 6 && !rc; c++) rc = film_alloc(f, q[c], P);
+        if (!rc) rc = film_alloc(f, &b.qpath[k], P);
+    }
+    if (!rc) rc = film_alloc(f, &b.hit_tri, P);
+    float** per_path[8] = {&b.hit_t, &b.hit_u, &b.hit_v, &b.rad_r, &b.rad_g, &b.rad_b, &b.thr, nullptr};
+    for (int c = 0; per_path[c] && !rc; c++) rc = film_alloc(f, per_path[c], P);
+    if (!rc) rc = film_alloc(f, &b.pixel, P);
+    if (!rc) rc = film_alloc(f, &b.sample, P);
+    float** per_sh[11] = {&b.sh.ox, &b.sh.oy, &b.sh.oz, &b.sh.dx, &b.sh.dy, &b.sh.dz, &b.sh_dist, &b.sh_wr, &b.sh_wg, &b.sh_wb, nullptr};
+    for (int c = 0; per_sh[c] && !rc; c++) rc = film_alloc(f, per_sh[c], S);
+    if (!rc) rc = film_alloc(f, &b.sh_vis, S);
+    if (!rc) rc = film_alloc(f, &b.cnt, (size_t)CNT_WORDS);
+    if (!rc) rc = film_alloc(f, &f->d_lights, (size_t)PT_MAX_LIGHTS);
+    if (!rc) rc = film_alloc(f, &f->d_sub, G);
+    if (!rc) rc = film_alloc(f, &f->d_groups, 2 * G + 2);
+    if (rc) { film_free_scratch(f); return rc; }
+    f->cap_paths = P; f->cap_lights = L; f->cap_sub = G;
+    return PT_OK;
+}
+
+static void fill_cam(CamParams& c, const pt_camera* cam, int width, int height) {
+    c.origin = v3(cam->origin[0], cam->origin[1], cam->origin[2]);
+    c.direction = v3(cam->direction[0], cam->direction[1], cam->direction[2]);
+    c.width = width; c.height = height;
+    cam_basis(c, v3(cam->up[0], cam->up[1], cam->up[2]));
+    c.image_plane_width = cam->image_plane_width;
+    c.plane_of_focus_distance = cam->plane_of_focus_distance;
+    c.dof_dispersion = cam->dof_dispersion;
+    c.sky = v3(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
+}
+
+/* Renders one batch (already clamped, grouped and numbered) with no host round trip. */
+static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, const std::vector<SubPass>& sub,
+                        uint32_t n_paths, uint64_t seed, uint64_t counts[3]) {
+    pt_scene* s = f->scene;
+    RenderBuffers& b = f->rb;
+    /* rectangle groups for the film kernel */
+    std::vector<uint32_t> g_entry, g_off;
+    uint32_t total = 0;
+    for (uint32_t e = 0; e < sub.size(); e++)
+        if (sub[e].group_first == e) { g_entry.push_back(e); g_off.push_back(total); total += sub[e].padded; }
+    g_off.push_back(total);
+    uint32_t n_groups = (uint32_t)g_entry.size();
+    HIP_TRY(hipMemcpyAsync(f->d_sub, sub.data(), sub.size() * sizeof(SubPass), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(f->d_groups, g_entry.data(), n_groups * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(f->d_groups + f->cap_sub, g_off.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, s->stream));
+    {
+        ScopedTimer tm(s, PT_KERNEL_GENERATE);
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, s->stream, cam, f->d_sub, (uint32_t)sub.size(),
+                           n_paths, seed, b);
+        HIP_TRY(hipGetLastError());
+    }
+    const int light_grid = s->num_cus * 8;
+    for (uint32_t depth = 0; depth <= 10; depth++) { /* cast_ray(ray, 10, 1): recursions 10..0 */
+        const int cur = depth & 1;
+        TraceArgs a{};
+        a.rays = {b.q[cur].ox, b.q[cur].oy, b.q[cur].oz, b.q[cur].dx, b.q[cur].dy, b.q[cur].dz};
+        a.d_count = b.cnt + CNT_QUEUE + depth;
+        a.d_next_chunk = b.cnt + CNT_CHUNK_CLOSEST + depth;
+        a.out_idx = b.hit_tri; a.out_t = b.hit_t; a.out_u = b.hit_u; a.out_v = b.hit_v;
+        int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a);
+        if (rc) return rc;
+        {
+            ScopedTimer tm(s, PT_KERNEL_SHADE);
+            hipLaunchKernelGGL(k_shade, dim3(light_grid), dim3(256), 0, s->stream, s->d, cam, f->d_lights, n_lights, depth,
+                               depth == 10 ? 1 : 0, seed, b);
+            HIP_TRY(hipGetLastError());
+        }
+        if (n_lights > 0) {
+            TraceArgs sa{};
+            sa.rays = {b.sh.ox, b.sh.oy, b.sh.oz, b.sh.dx, b.sh.dy, b.sh.dz};
+            sa.d_count = b.cnt + CNT_SHADOW + depth;
+            sa.d_next_chunk = b.cnt + CNT_CHUNK_ANY + depth;
+            sa.dist = b.sh_dist; sa.vis = b.sh_vis;
+            rc = launch_trace<TRACE_SHADOW_ANY>(s, sa);
+            if (rc) return rc;
+            sa.d_next_chunk = b.cnt + CNT_CHUNK_EXACT + depth;
+            rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa);
+            if (rc) return rc;
+            ScopedTimer tm(s, PT_KERNEL_ACCUMULATE);
+            hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, s->stream, n_lights, depth, b);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    {
+        ScopedTimer tm(s, PT_KERNEL_ACCUMULATE);
+        hipLaunchKernelGGL(k_film, dim3((total + 255) / 256), dim3(256), 0, s->stream, f->d_sub, (uint32_t)sub.size(), f->d_groups,
+                           f->d_groups + f->cap_sub, n_groups, total, f->width, f->d_film, b);
+        HIP_TRY(hipGetLastError());
+    }
+    if (counts) {
+        uint32_t h[CNT_WORDS];
+        HIP_TRY(hipMemcpyAsync(h, b.cnt, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        counts[0] += h[CNT_SAMPLES];
+        for (int d = 0; d <= 10; d++) { counts[1] += h[CNT_QUEUE + d]; counts[2] += h[CNT_SHADOW + d]; }
+    }
+    return PT_OK;
+}
+
+extern "C" {
+
+int pt_film_create(pt_scene* s, int width, int height, float* d_external, pt_film** out) {
+    if (!s || !out) return fail(PT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (int64_t)width * height > ((int64_t)1 << 28)) return fail(PT_ERR_INVALID, "bad film size");
+    int rc = set_device(s);
+    if (rc) return rc;
+    pt_film* f = new pt_film();
+    f->scene = s; f->width = width; f->height = height;
+    if (d_external) { f->d_film = (float4*)d_external; f->owns = false; }
+    else {
+        if (hipMalloc((void**)&f->d_film, (size_t)width * height * sizeof(float4)) != hipSuccess) { delete f; return fail(PT_ERR_DEVICE, "hipMalloc failed for the film"); }
+        f->owns = true;
+        if (hipMemsetAsync(f->d_film, 0, (size_t)width * height * sizeof(float4), s->stream) != hipSuccess) { (void)hipFree(f->d_film); delete f; return fail(PT_ERR_DEVICE, "hipMemset failed"); }
+    }
+    *out = f;
+    return PT_OK;
+}
+
+void pt_film_destroy(pt_film* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->scene->device);
+    (void)hipStreamSynchronize(f->scene->stream);
+    film_free_scratch(f);
+    if (f->owns && f->d_film) (void)hipFree(f->d_film);
+    delete f;
+}
+
+int pt_film_zero(pt_film* f) {
+    if (!f) return fail(PT_ERR_INVALID, "null film");
+    int rc = set_device(f->scene);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(f->d_film, 0, (size_t)f->width * f->height * sizeof(float4), f->scene->stream));
+    return PT_OK;
+}
+
+float* pt_film_device_ptr(pt_film* f) { return f ? (float*)f->d_film : nullptr; }
+
+int pt_film_read(pt_film* f, float* rgb_sum, int32_t* passes) {
+    if (!f || !rgb_sum || !passes) return fail(PT_ERR_INVALID, "null argument");
+    pt_scene* s = f->scene;
+    int rc = set_device(s);
+    if (rc) return rc;
+    size_t n = (size_t)f->width * f->height;
+    DevBuf d_rgb, d_p;
+    rc = d_rgb.alloc(n * 12); if (rc) return rc;
+    rc = d_p.alloc(n * 4); if (rc) return rc;
+    hipLaunchKernelGGL(k_film_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, f->d_film, n, (float*)d_rgb.p, (int32_t*)d_p.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_sum, d_rgb.p, n * 12, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(passes, d_p.p, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, int n_lights, const pt_tile_pass* passes,
+                     int n_passes, uint64_t seed, pt_render_stats* stats) {
+    if (!f || !cam || n_passes < 0 || (n_passes > 0 && !passes) || n_lights < 0 || (n_lights > 0 && !lights))
+        return fail(PT_ERR_INVALID, "bad argument");
+    if (n_lights > PT_MAX_LIGHTS) return fail(PT_ERR_LIMIT, "more than PT_MAX_LIGHTS lights");
+    pt_scene* s = f->scene;
+    int rc = set_device(s);
+    if (rc) return rc;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, s->stream));
+    }
+    CamParams cp;
+    fill_cam(cp, cam, f->width, f->height);
+    const size_t limit = batch_paths_limit();
+    /* PassDescriptor::clamp_bounds (reference integrator.cpp:164-183), then split into batches */
+    std::vector<SubPass> batch;
+    size_t batch_paths = 0;
+    uint64_t counts[3] = {0, 0, 0};
+    DLight hl[PT_MAX_LIGHTS];
+    for (int l = 0; l < n_lights; l++) {
+        hl[l].pos = v3(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
+        hl[l].color = v3(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
+    }
+    bool lights_uploaded = false;
+    auto flush = [&]() -> int {
+        if (batch.empty()) return PT_OK;
+        size_t cap = 65536;
+        while (cap < batch_paths) cap <<= 1;
+        int r2 = film_ensure_scratch(f, cap, (uint32_t)n_lights, batch.size());
+        if (r2) return r2;
+        if (!lights_uploaded && n_lights > 0) {
+            HIP_TRY(hipMemcpyAsync(f->d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, s->stream));
+            lights_uploaded = true;
+        }
+        r2 = render_batch(f, cp, (uint32_t)n_lights, batch, (uint32_t)batch_paths, seed, stats ? counts : nullptr);
+        /* the host vectors of this batch must outlive the async copies */
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        batch.clear(); batch_paths = 0;
+        return r2;
+    };
+    for (int i = 0; i < n_passes; i++) {
+        pt_tile_pass p = passes[i];
+        if (p.x < 0) p.x = 0;
+        if (p.y < 0) p.y = 0;
+        if (p.x > f->width - 1) p.x = f->width - 1;
+        if (p.y > f->height - 1) p.y = f->height - 1;
+        if (p.w == -1) p.w = f->width;
+        if (p.h == -1) p.h = f->height;
+        if (p.w > f->width - p.x) p.w = f->width - p.x;
+        if (p.h > f->height - p.y) p.h = f->height - p.y;
+        if (p.w <= 0 || p.h <= 0 || p.n_samples == 0) continue;
+        uint32_t bx = (uint32_t)(p.w + 7) / 8, by = (uint32_t)(p.h + 7) / 8;
+        size_t padded = (size_t)bx * by * 64;
+        if (padded > limit) return fail(PT_ERR_LIMIT, "one pass of this rectangle exceeds PT_BATCH_PATHS");
+        uint32_t done = 0;
+        while (done < p.n_samples) {
+            size_t room = (limit - batch_paths) / padded;
+            /* a different rectangle overlapping one already in the batch would race in the film kernel */
+            bool overlap = false;
+            for (const SubPass& e : batch)
+                if (!(e.x == p.x && e.y == p.y && e.w == p.w && e.h == p.h) &&
+                    p.x < e.x + e.w && e.x < p.x + p.w && p.y < e.y + e.h && e.y < p.y + p.h) { overlap = true; break; }
+            if (room == 0 || overlap || batch.size() >= 16384) { rc = flush(); if (rc) return rc; continue; }
+            uint32_t take = (uint32_t)std::min<size_t>(room, p.n_samples - done);
+            SubPass sp{};
+            sp.x = p.x; sp.y = p.y; sp.w = p.w; sp.h = p.h;
+            sp.first_sample = p.first_sample + done; sp.n_samples = take;
+            sp.blocks_x = bx; sp.padded = (uint32_t)padded; sp.path0 = (uint32_t)batch_paths;
+            sp.group_first = (uint32_t)batch.size();
+            for (uint32_t e = 0; e < batch.size(); e++)
+                if (batch[e].x == p.x && batch[e].y == p.y && batch[e].w == p.w && batch[e].h == p.h) { sp.group_first = batch[e].group_first; break; }
+            batch.push_back(sp);
+            batch_paths += padded * take;
+            done += take;
+        }
+    }
+    rc = flush();
+    if (rc) return rc;
+    if (stats) {
+        HIP_TRY(hipEventRecord(ev1, s->stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        stats->camera_samples = counts[0]; stats->closest_rays = counts[1]; stats->shadow_rays = counts[2];
+        stats->gpu_ms = ms;
+    }
+    return PT_OK;
+}
+
+int pt_camera_rays_dev(pt_scene* s, const pt_camera* cam, int width, int height, int x, int y, int w, int h, int jittered,
+                       uint32_t sample, uint64_t seed, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz) {
+    if (!s || !cam || !ox || !oy || !oz || !dx || !dy || !dz) return fail(PT_ERR_INVALID, "null argument");
+    if (width <= 0 || height <= 0 || w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > width || y + h > height)
+        return fail(PT_ERR_INVALID, "rectangle outside the image");
+    int rc = set_device(s);
+    if (rc) return rc;
+    CamParams cp;
+    fill_cam(cp, cam, width, height);
+    RaySoAW out = {ox, oy, oz, dx, dy, dz};
+    ScopedTimer tm(s, PT_KERNEL_GENERATE);
+    hipLaunchKernelGGL(k_camera_rays, dim3(((unsigned)(w * h) + 255) / 256), dim3(256), 0, s->stream, cp, x, y, w, h, jittered, sample, seed, out);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+} // extern "C"

@@ -297,7 +297,7 @@ struct Flat {
 };
 
 uint32_t leaf_ref(const BNode* n) {
-    uint32_t cnt = n->count <= 31 ? (uint32_t)n->count : 0u;
+    uint32_t cnt = n->count <= (int64_t)PT_REF_COUNT_MASK ? (uint32_t)n->count : 0u;
     return PT_REF_LEAF | (cnt << PT_REF_COUNT_SHIFT) | (uint32_t)n->begin;
 }
 

@@ -108,6 +108,14 @@ def hip_lib():
         if not os.path.exists(HIP_LIB):
             raise RuntimeError(f"{HIP_LIB} is missing: run `make hip` (or __graft_entry__.build()); "
                                "there is no CPU fallback for the GPU path")
+        if os.environ.get("PT_NO_TORCH") != "1":
+            # torch bundles its own HIP runtime (same soname).  Two HIP runtimes in one process
+            # cannot both see the GPU, so when torch is going to be used for device memory it has
+            # to be loaded first; libpt_hip.so then binds to the runtime torch brought in.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(HIP_LIB)
         vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
         L.pt_device_count.argtypes = [C.POINTER(i32)]

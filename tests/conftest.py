@@ -1,0 +1,129 @@
+"""Shared fixtures.  Tests marked `gpu` need an MI355X and call through the C ABI of
+libpt_hip.so; everything else runs on the CPU (oracle, host-side builder, lane emulation)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import orc  # noqa: E402  (the CPU oracle: checker only)
+import path_tracing_amd as pta  # noqa: E402
+
+
+def rays_sphere(n, seed=1234, radius=3.0):
+    """Origins uniform on a sphere, aimed at points uniform in the unit ball (incoherent set)."""
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3))
+    o = radius * o / np.linalg.norm(o, axis=1, keepdims=True)
+    t = rng.normal(size=(n, 3))
+    t = t / np.linalg.norm(t, axis=1, keepdims=True) * rng.random((n, 1)) ** (1.0 / 3.0)
+    d = (t - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+def rays_inside(n, seed=5):
+    rng = np.random.default_rng(seed)
+    o = (rng.random((n, 3)) * 2 - 1).astype(np.float32) * np.array([1.3, 0.8, 1.0], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def rays_axis_parallel(n, seed=6):
+    rng = np.random.default_rng(seed)
+    o = (rng.random((n, 3)) * 4 - 2).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    d[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    return o, d
+
+
+def rays_at_vertices(tris, n, seed=7, radius=3.0):
+    """Rays aimed exactly at mesh vertices and edge midpoints (shared-edge / crack cases)."""
+    rng = np.random.default_rng(seed)
+    t = tris.reshape(-1, 3, 3)
+    k = rng.integers(0, t.shape[0], n)
+    a = t[k, rng.integers(0, 3, n)]
+    b = t[k, rng.integers(0, 3, n)]
+    target = np.where(rng.random((n, 1)) < 0.5, a, 0.5 * (a + b))
+    o = rng.normal(size=(n, 3))
+    o = (radius * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+def all_ray_sets(tris, n=20000):
+    cam = orc.cli_camera()
+    sets = {
+        "primary": orc.camera_rays(cam, 160, 120),
+        "sphere": rays_sphere(n),
+        "inside": rays_inside(n),
+        "axis": rays_axis_parallel(n),
+        "vertices": rays_at_vertices(tris, n),
+    }
+    return sets
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_hits_equal(a, b, what=""):
+    names = ("index", "t", "u", "v")
+    for x, y, nm in zip(a, b, names):
+        bad = np.nonzero(bits(x) != bits(y))[0]
+        assert bad.size == 0, f"{what}: {bad.size} rays differ in {nm}, first {bad[:5]}: {x[bad[:5]]} vs {y[bad[:5]]}"
+
+
+class SceneSet:
+    def __init__(self, level, floor_n=None):
+        self.tris = pta.meshgen.standin_scene(level, floor_n)
+        self.oracle = orc.Scene(self.tris, threads=8)
+        self.host = pta.HostScene(self.tris, threads=8)
+        self._gpu = None
+
+    @property
+    def gpu(self):
+        if self._gpu is None:
+            self._gpu = pta.GpuScene(self.host, 0)
+        return self._gpu
+
+
+@pytest.fixture(scope="session")
+def scene_small():
+    return SceneSet(3)          # 1 312 triangles
+
+
+@pytest.fixture(scope="session")
+def scene_medium():
+    return SceneSet(5)          # 20 992 triangles
+
+
+@pytest.fixture(scope="session")
+def scene_tiny():
+    return SceneSet(0)          # 28 triangles: tree of depth 3
+
+
+def load_emul():
+    path = os.path.join(ROOT, "tests", "native", "_build", "libtraverse_emul.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.check_call(["make", "-C", ROOT, "-s", "native-tests"])
+    E = C.CDLL(path)
+    vp = C.c_void_p
+    E.emul_raycast_closest.argtypes = [vp, C.c_uint64] + [vp] * 7
+    E.emul_raycast_shadow.argtypes = [vp, C.c_uint64] + [vp] * 4
+    return E

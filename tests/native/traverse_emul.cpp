@@ -1,0 +1,105 @@
+/*
+ * traverse_emul.cpp -- lane-level emulation of the device tree walk on the CPU.
+ *
+ * TEST HARNESS ONLY.  Compiles path_tracing_amd/csrc/traverse_core.h (the per-lane logic the
+ * HIP kernels run) with g++ and drives it one ray at a time over a pt_flat_scene, so that the
+ * CPU test-suite can compare the kernel's logic with the oracle without a GPU.  Nothing in
+ * the product loads this library.
+ */
+#include <cstring>
+#include <vector>
+
+#include "pt_hip.h"
+#include "traverse_core.h"
+
+namespace {
+
+struct CpuMem {
+    const pt_flat_node* nodes;
+    const pt_tri_isect* tris;
+    void load_node(uint32_t i, ptc::NodeData& n) const {
+        const pt_flat_node& s = nodes[i];
+        for (int k = 0; k < 3; k++) { n.lo_min[k] = s.lo_min[k]; n.lo_max[k] = s.lo_max[k]; n.hi_min[k] = s.hi_min[k]; n.hi_max[k] = s.hi_max[k]; }
+        n.lo_ref = s.lo_ref; n.hi_ref = s.hi_ref; n.axis = s.axis;
+    }
+    void load_tri(uint32_t k, ptc::TriData& t) const {
+        const pt_tri_isect& s = tris[k];
+        t.p0x = s.p0[0]; t.p0y = s.p0[1]; t.p0z = s.p0[2];
+        t.e1x = s.e1[0]; t.e1y = s.e1[1]; t.e1z = s.e1[2];
+        t.e2x = s.e2[0]; t.e2y = s.e2[1]; t.e2z = s.e2[2];
+        t.mesh_index = s.mesh_index; t.leaf_count = s.leaf_count;
+    }
+};
+
+struct CpuStack {
+    uint32_t data[3 * PT_MAX_TREE_DEPTH + 4];
+    int sp = 0, max_sp = 0;
+    bool overflow = false;
+    void push(uint32_t v) {
+        if (sp >= (int)(sizeof(data) / sizeof(data[0]))) { overflow = true; return; }
+        data[sp++] = v;
+        if (sp > max_sp) max_sp = sp;
+    }
+    uint32_t pop() { return data[--sp]; }
+};
+
+ptc::RootBox root_of(const pt_flat_scene* sc) {
+    ptc::RootBox b;
+    b.mnx = sc->root_min[0]; b.mny = sc->root_min[1]; b.mnz = sc->root_min[2];
+    b.mxx = sc->root_max[0]; b.mxy = sc->root_max[1]; b.mxz = sc->root_max[2];
+    return b;
+}
+
+} // namespace
+
+extern "C" {
+
+/* Returns the largest stack use (dwords) seen, or -1 on overflow. */
+int emul_raycast_closest(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, int32_t* idx, float* t,
+                         float* u, float* v, int32_t* flat_pos) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    int worst = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        ptc::Ray9 r;
+        r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
+        r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
+        ptc::ray_set_recip(r);
+        CpuStack st;
+        ptc::Hit h;
+        bool found = sc->n_tris != 0 && ptc::trace_lane<false>(mem, sc->root_ref, root_of(sc), r, st, h);
+        if (st.overflow) return -1;
+        if (st.max_sp > worst) worst = st.max_sp;
+        if (found) { idx[i] = (int32_t)h.mesh; t[i] = h.t; u[i] = h.u; v[i] = h.v; if (flat_pos) flat_pos[i] = (int32_t)h.tri; }
+        else { idx[i] = -1; t[i] = u[i] = v[i] = 0.0f; if (flat_pos) flat_pos[i] = -1; }
+    }
+    return worst;
+}
+
+int emul_raycast_shadow(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const float* dist,
+                        uint8_t* visible) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    int worst = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        ptc::Ray9 r;
+        r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
+        r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
+        ptc::ray_set_recip(r);
+        CpuStack st;
+        ptc::Hit h;
+        bool vis;
+        if (sc->n_tris == 0) vis = true;
+        else if (dist[i] >= 1.0f) {
+            /* v <= 1 <= dist for every hit, so any hit occludes */
+            vis = !ptc::trace_lane<true>(mem, sc->root_ref, root_of(sc), r, st, h);
+        } else {
+            bool found = ptc::trace_lane<false>(mem, sc->root_ref, root_of(sc), r, st, h);
+            vis = !found || h.v > dist[i];
+        }
+        if (st.overflow) return -1;
+        if (st.max_sp > worst) worst = st.max_sp;
+        visible[i] = vis ? 1 : 0;
+    }
+    return worst;
+}
+
+} // extern "C"

@@ -1,0 +1,35 @@
+"""The C-ABI library loads and exports every symbol include/pt_hip.h declares (no compute)."""
+import ctypes as C
+import os
+import re
+
+from conftest import ROOT
+from path_tracing_amd import native
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pth?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_header():
+    names = _declared("pt_hip.h")
+    assert set(names) == set(native.HIP_SYMBOLS), set(names) ^ set(native.HIP_SYMBOLS)
+    lib = C.CDLL(native.HIP_LIB)
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.pt_build_info.restype = C.c_char_p
+    assert b"gfx950" in lib.pt_build_info()
+
+
+def test_host_library_exports_header():
+    lib = C.CDLL(native.HOST_LIB)
+    for n in _declared("pt_host.h"):
+        assert hasattr(lib, n), n
+
+
+def test_record_sizes_match_header():
+    assert C.sizeof(native.FlatNode) == 64
+    assert native.NODE_DTYPE.itemsize == 64 and native.ISECT_DTYPE.itemsize == 48 and native.SHADE_DTYPE.itemsize == 64
+    assert C.sizeof(native.Camera) == 15 * 4 and C.sizeof(native.Light) == 24 and C.sizeof(native.TilePass) == 24

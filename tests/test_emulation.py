@@ -1,0 +1,70 @@
+"""The per-lane device logic (path_tracing_amd/csrc/traverse_core.h), compiled for the CPU and
+run one ray at a time over the flattened arrays, against the recursive oracle: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import all_ray_sets, assert_hits_equal, load_emul, orc, pta
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def emul_closest(E, host, o, d):
+    o = np.ascontiguousarray(o, np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    n = len(o)
+    idx = np.empty(n, np.int32)
+    t = np.empty(n, np.float32)
+    u = np.empty(n, np.float32)
+    v = np.empty(n, np.float32)
+    pos = np.empty(n, np.int32)
+    flat = host.flat
+    worst = E.emul_raycast_closest(C.byref(flat), n, _p(o), _p(d), _p(idx), _p(t), _p(u), _p(v), _p(pos))
+    return (idx, t, u, v), worst, pos
+
+
+@pytest.mark.parametrize("which", ["scene_tiny", "scene_small", "scene_medium"])
+def test_lane_walk_bit_exact(which, request):
+    sc = request.getfixturevalue(which)
+    E = load_emul()
+    for name, (o, d) in all_ray_sets(sc.tris).items():
+        got, worst, pos = emul_closest(E, sc.host, o, d)
+        assert 0 <= worst <= 3 * 20, "stack bound"
+        assert_hits_equal(got, sc.oracle.raycast(o, d), f"{which}/{name}")
+        # leaf-order position and mesh index agree through the permutation
+        _, tris, _ = sc.host.flat_arrays()
+        hit = pos >= 0
+        assert np.array_equal(tris["mesh_index"][pos[hit]].astype(np.int32), got[0][hit])
+
+
+def test_lane_shadow(scene_small, scene_medium):
+    E = load_emul()
+    for sc in (scene_small, scene_medium):
+        for name, (o, d) in all_ray_sets(sc.tris, 6000).items():
+            rng = np.random.default_rng(3)
+            dist = np.where(rng.random(len(o)) < 0.5, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
+            vis = np.empty(len(o), np.uint8)
+            flat = sc.host.flat
+            o32 = np.ascontiguousarray(o, np.float32)
+            d32 = np.ascontiguousarray(d, np.float32)
+            worst = E.emul_raycast_shadow(C.byref(flat), len(o), _p(o32), _p(d32), _p(dist), _p(vis))
+            assert worst >= 0
+            assert np.array_equal(vis, sc.oracle.shadow_visible(o, d, dist)), name
+
+
+def test_oversized_leaf(scene_small):
+    """Leaves with more than 15 triangles keep their count in the first triangle record."""
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)
+    t = np.repeat(one, 40, axis=0)
+    t[:, 2::3] += np.linspace(0, 0.5, 40, dtype=np.float32)[:, None]   # stack them along z, same x/y boxes
+    host = pta.HostScene(t)
+    oracle = orc.Scene(t)
+    E = load_emul()
+    o = np.array([[0.2, 0.2, 5.0], [0.2, 0.2, -5.0], [0.9, 0.9, 5.0]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0, 0, -1]], np.float32)
+    got, _, _ = emul_closest(E, host, o, d)
+    assert_hits_equal(got, oracle.raycast(o, d))
+    assert got[0][0] >= 0 and got[0][2] == -1

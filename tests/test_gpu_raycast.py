@@ -1,0 +1,109 @@
+"""GPU parity of the ray-casting entry points, through the C ABI, against the CPU oracle.
+Bar: bit-exact triangle index, t, u, v (integer/bit equality, no tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import all_ray_sets, assert_hits_equal, orc, pta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("which", ["scene_tiny", "scene_small", "scene_medium"])
+def test_closest_hit_bit_exact(which, request):
+    sc = request.getfixturevalue(which)
+    for name, (o, d) in all_ray_sets(sc.tris).items():
+        want = sc.oracle.raycast(o, d)
+        got = sc.gpu.raycast_closest(o, d)
+        assert_hits_equal(got, want, f"{which}/{name}")
+
+
+def test_closest_hit_ragged_sizes(scene_small):
+    sc = scene_small
+    o, d = all_ray_sets(sc.tris, 3000)["sphere"]
+    for n in (1, 63, 64, 65, 257, 2999):
+        assert_hits_equal(sc.gpu.raycast_closest(o[:n], d[:n]), sc.oracle.raycast(o[:n], d[:n]), f"n={n}")
+    # empty input is a no-op
+    got = sc.gpu.raycast_closest(o[:0], d[:0])
+    assert all(x.size == 0 for x in got)
+
+
+def test_shadow_visibility(scene_small, scene_medium):
+    for sc in (scene_small, scene_medium):
+        for name, (o, d) in all_ray_sets(sc.tris, 8000).items():
+            rng = np.random.default_rng(11)
+            # light distances on both sides of 1: below 1 the reference's swapped out-parameters
+            # make the answer depend on the closest hit's barycentric v
+            dist = np.where(rng.random(len(o)) < 0.5, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
+            want = sc.oracle.shadow_visible(o, d, dist)
+            got = sc.gpu.raycast_shadow(o, d, dist)
+            assert np.array_equal(got, want), f"{name}: {(got != want).sum()} differ"
+
+
+def test_empty_scene_misses():
+    host = pta.HostScene(np.zeros((0, 9), np.float32))
+    gpu = pta.GpuScene(host, 0)
+    o = np.zeros((100, 3), np.float32)
+    d = np.tile(np.array([[0, 0, 1]], np.float32), (100, 1))
+    idx, t, u, v = gpu.raycast_closest(o, d)
+    assert (idx == -1).all() and (t == 0).all()
+    assert (gpu.raycast_shadow(o, d, np.full(100, 2.0, np.float32)) == 1).all()
+
+
+def test_camera_rays_bit_exact(scene_small):
+    import torch
+    sc = scene_small
+    W, H = 96, 64
+    for dof in (0.0, 0.1):
+        cam_o = orc.cli_camera(dof_aperture=dof, dof_distance=4.5)
+        cam_g = pta.cli_camera(dof_aperture=dof, dof_distance=4.5)
+        for jittered, sample in ((0, 0), (1, 0), (1, 7)):
+            out = [torch.empty(W * H, dtype=torch.float32, device="cuda") for _ in range(6)]
+            sc.gpu.camera_rays_dev(cam_g, W, H, (0, 0, W, H), jittered, sample, 99, out)
+            sc.gpu.sync()
+            got = np.stack([t.cpu().numpy() for t in out], axis=1)
+            o, d = orc.camera_rays(cam_o, W, H, None, bool(jittered), sample, 99)
+            want = np.concatenate([o, d], axis=1)
+            bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0]
+            assert bad.size == 0, f"dof={dof} jittered={jittered}: {bad.size} rays differ, e.g. {got[bad[:2]]} vs {want[bad[:2]]}"
+
+
+def test_render_matches_oracle(scene_small):
+    sc = scene_small
+    W, H, S = 96, 64, 4
+    cam_o = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    cam_g = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    want_rgb, want_p, want_counts = sc.oracle.render(cam_o, orc.cli_lights(), W, H, None, 0, S, seed=3)
+    film = pta.Film(sc.gpu, W, H)
+    st = film.render(cam_g, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=3)
+    rgb, passes = film.read()
+    assert np.array_equal(passes, want_p)
+    assert st.camera_samples == W * H * S
+    assert st.closest_rays == int(want_counts[0]) and st.shadow_rays == int(want_counts[1])
+    # Paths are identical ray for ray (same hits, same random stream); only the order in which
+    # the bounce terms are summed differs (0.8*(0.8*x) nested in the oracle, a running
+    # throughput on the GPU), so the tolerance is a few ulp of the pixel value.
+    err = np.abs(rgb - want_rgb)
+    tol = 1e-5 * np.maximum(np.abs(want_rgb), 1.0)
+    assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    rmse = float(np.sqrt(np.mean((rgb / S - want_rgb / S) ** 2)))
+    assert rmse < 1e-6, rmse
+
+
+def test_render_tiling_invariance(scene_small):
+    """The image does not depend on how passes are cut into tiles or batches."""
+    sc = scene_small
+    W, H, S = 80, 48, 3
+    cam = pta.cli_camera(dof_aperture=0.05, dof_distance=4.5)
+    film = pta.Film(sc.gpu, W, H)
+    film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=5)
+    full, _ = film.read()
+    film.zero()
+    tiles = []
+    for s in range(S):
+        for y in range(0, H, 32):
+            for x in range(0, W, 32):
+                tiles.append((x, y, 32, 32, s, 1))
+    film.render(cam, pta.cli_lights(), tiles, seed=5)
+    tiled, passes = film.read()
+    assert (passes == S).all()
+    assert np.array_equal(full.view(np.uint32), tiled.view(np.uint32))

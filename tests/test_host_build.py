@@ -1,0 +1,110 @@
+"""Host-side scene preparation (libpt_host.so) against the oracle: same mesh data, same tree,
+bit for bit; and the flattened arrays are a faithful re-encoding of that tree."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import bits, orc, pta
+from path_tracing_amd import native
+
+
+@pytest.mark.parametrize("which", ["scene_tiny", "scene_small", "scene_medium"])
+def test_tree_and_triangle_data_identical(which, request):
+    sc = request.getfixturevalue(which)
+    assert sc.host.tree_stats() == sc.oracle.tree_stats()
+    n1, l1 = sc.oracle.tree_dump()
+    n2, l2 = sc.host.tree_dump()
+    assert np.array_equal(bits(n1), bits(n2))
+    assert np.array_equal(l1, l2)
+    assert np.array_equal(bits(sc.oracle.triangle_data()), bits(sc.host.triangle_data()))
+
+
+def test_build_is_thread_count_independent(scene_medium):
+    a = pta.HostScene(scene_medium.tris, threads=1)
+    b = pta.HostScene(scene_medium.tris, threads=7)
+    na, la = a.tree_dump()
+    nb, lb = b.tree_dump()
+    assert np.array_equal(bits(na), bits(nb)) and np.array_equal(la, lb)
+
+
+def _walk(nodes, ref, depth, out):
+    if ref & native.PT_REF_LEAF:
+        out.append((depth, ref & native.PT_REF_START_MASK, (ref >> native.PT_REF_COUNT_SHIFT) & 0xF))
+        return
+    n = nodes[ref]
+    _walk(nodes, int(n["lo_ref"]), depth + 1, out)
+    _walk(nodes, int(n["hi_ref"]), depth + 1, out)
+
+
+@pytest.mark.parametrize("which", ["scene_tiny", "scene_small", "scene_medium"])
+def test_flat_arrays_encode_the_tree(which, request):
+    sc = request.getfixturevalue(which)
+    nodes, tris, shade = sc.host.flat_arrays()
+    flat = sc.host.flat
+    dump, leaves = sc.host.tree_dump()
+    st = sc.host.tree_stats()
+    assert flat.n_tris == sc.host.n and flat.n_nodes == st["nodes"] - st["leaves"]
+    assert flat.max_depth == st["max_depth"]
+    # leaf order of the triangle array == leaf order of the tree dump
+    assert np.array_equal(tris["mesh_index"].astype(np.int32), leaves)
+    # leaves reached left-to-right cover [0, n) contiguously, and counts match the dump
+    found = []
+    _walk(nodes, int(flat.root_ref), 0, found)
+    leaf_counts = dump[dump[:, 0] == 1][:, 9].astype(int)
+    pos = 0
+    for (depth, start, cnt4), want in zip(found, leaf_counts):
+        assert start == pos
+        assert cnt4 == (want if want <= 15 else 0)
+        assert tris["leaf_count"][start] == want
+        pos += want
+    assert pos == sc.host.n and len(found) == len(leaf_counts)
+    # per-triangle records are the oracle's Triangle fields, permuted
+    td = sc.oracle.triangle_data()[leaves]
+    assert np.array_equal(bits(tris["p0"]), bits(td[:, 0:3]))
+    assert np.array_equal(bits(tris["e1"]), bits(td[:, 9:12])) and np.array_equal(bits(tris["e2"]), bits(td[:, 12:15]))
+    assert np.array_equal(bits(shade["normal"]), bits(td[:, 15:18])) and np.array_equal(bits(shade["plane"]), bits(td[:, 27]))
+    assert np.array_equal(bits(shade["base_n"]), bits(td[:, 18:21]))
+    assert np.array_equal(bits(shade["u_n"]), bits(td[:, 21:24])) and np.array_equal(bits(shade["v_n"]), bits(td[:, 24:27]))
+    # interior nodes carry their children's boxes: compare with the pre-order dump
+    interior = dump[dump[:, 0] == 0]
+    assert np.array_equal(nodes["axis"], interior[:, 1].astype(np.uint32))   # both are pre-order over interior nodes
+
+
+def test_stl_round_trip_and_errors(scene_small):
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "m.stl")
+        pta.meshgen.write_stl(path, scene_small.tris)
+        assert np.array_equal(pta.meshgen.read_stl(path), scene_small.tris)
+        h = pta.HostScene(stl_path=path)
+        o = orc.Scene(stl_path=path)
+        assert np.array_equal(bits(h.tree_dump()[0]), bits(o.tree_dump()[0]))
+        assert np.array_equal(bits(h.tree_dump()[0]), bits(scene_small.host.tree_dump()[0]))
+        with pytest.raises(RuntimeError):
+            pta.HostScene(stl_path=os.path.join(tmp, "missing.stl"))
+        # truncated file and non-zero attribute count are rejected (stlreader.cpp:25-38 asserts)
+        raw = open(path, "rb").read()
+        open(os.path.join(tmp, "short.stl"), "wb").write(raw[:-7])
+        with pytest.raises(RuntimeError):
+            pta.HostScene(stl_path=os.path.join(tmp, "short.stl"))
+        bad = bytearray(raw)
+        bad[84 + 48] = 1
+        open(os.path.join(tmp, "attr.stl"), "wb").write(bytes(bad))
+        with pytest.raises(RuntimeError):
+            pta.HostScene(stl_path=os.path.join(tmp, "attr.stl"))
+
+
+def test_degenerate_inputs():
+    # empty mesh: one empty leaf, no nodes
+    h = pta.HostScene(np.zeros((0, 9), np.float32))
+    assert h.n == 0 and h.flat.n_nodes == 0
+    # a single triangle, and many copies of the same triangle (the "no improvement" rule,
+    # kdtree.cpp:206-208, must stop the recursion in one oversized leaf)
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)
+    for reps in (1, 40):
+        t = np.repeat(one, reps, axis=0)
+        h = pta.HostScene(t)
+        o = orc.Scene(t)
+        assert h.tree_stats() == o.tree_stats()
+        assert h.tree_stats()["leaves"] == 1 and h.tree_stats()["largest_leaf"] == reps
