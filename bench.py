@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-casting hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric "Mrays/s (all bounces)" is
+quoted on): full path trace of the ~1.3 M-triangle stand-in object on its floor, 3 lights,
+mirror bounces (the reference's HEAD behaviour), Gaussian-aperture depth of field,
+1920x1080.  One step = one batch of --spp-per-step full-frame sample passes.  With N GPUs
+every rank renders its own sample range into its own film (weak scaling: per-GPU work is
+fixed) and the films are summed to rank 0 by one RCCL reduce inside the timed region.
+
+Prints ONE JSON line on rank 0.  `value` counts what the reference's `rays_cast++`
+(kdtree.cpp:578) would count -- closest-hit plus shadow casts -- per second of wall time,
+with scene and film resident in HBM before the clock starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--level", type=int, default=8, help="icosphere subdivision level of the stand-in mesh (8 -> 1.31 M)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def host_threads(world):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 8
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if env > 0:
+        avail = min(avail, env)
+    return max(1, min(16, avail // max(world, 1)) or 1)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    import path_tracing_amd as pta
+    from path_tracing_amd import native
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, spp = args.width, args.height, args.spp_per_step
+    t0 = time.time()
+    tris = pta.meshgen.standin_scene(args.level)
+    host = pta.HostScene(tris, threads=host_threads(world))
+    t_prepare = time.time() - t0
+    gpu = pta.GpuScene(host, local_rank)
+    film_t = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    film = pta.Film(gpu, W, H, external=film_t)
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    lights = pta.cli_lights()
+
+    total_steps = args.warmup + args.steps
+
+    def step(i):
+        first = (rank * total_steps + i) * spp
+        return film.render(cam, lights, [(0, 0, -1, -1, first, spp)], seed=args.seed, want_stats=True)
+
+    for i in range(args.warmup):
+        step(i)
+    gpu.sync()
+    film.zero()
+    for c in range(5):
+        gpu.kernel_time(c, reset=True)
+    gpu.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    closest = shadow = samples = 0
+    for i in range(args.warmup, total_steps):
+        st = step(i)
+        closest += st.closest_rays
+        shadow += st.shadow_rays
+        samples += st.camera_samples
+    gpu.sync()
+    if world > 1:
+        dist.reduce(film_t, dst=0, op=dist.ReduceOp.SUM)  # Canvas::add_from over all workers
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+
+    tot = torch.tensor([float(closest), float(shadow), float(samples)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    closest_all, shadow_all, samples_all = [float(x) for x in tot.cpu()]
+    elapsed = float(tmax.cpu()[0])
+
+    kt = {c: gpu.kernel_time(c) for c in range(5)}
+
+    if rank == 0:
+        rays_all = closest_all + shadow_all
+        value = rays_all / elapsed / 1e6
+        # sanity of the reduced film: every pixel got every rank's passes
+        passes = film_t.view(H, W, 4)[..., 3]
+        expect = float(args.steps * spp * world)
+        film_ok = bool((passes == expect).all().item())
+
+        out = {
+            "metric": "Mrays/s (all bounces)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "full path trace (configs[2]): stand-in bumpy icosphere level %d + floor, %d triangles, "
+                            "3 lights, mirror bounces <= 10, DOF 0.1/4.5, %dx%d, %d spp per step per GPU"
+                            % (args.level, host.n, W, H, spp),
+                "triangles": host.n, "width": W, "height": H, "spp_per_step": spp,
+                "parallelism": "sample-partitioned x%d, one RCCL reduce of the film" % world,
+            },
+            "camera_samples_per_s": round(samples_all / elapsed, 1),
+            "wall_s_1080p_1000spp_extrapolated": round(elapsed / samples_all * 1920 * 1080 * 1000, 2),
+            "rays_per_sample": round(rays_all / samples_all, 4),
+            "film_check": film_ok,
+            "scene_prepare_s": round(t_prepare, 2),
+            "kernel_ms": {name: {"ms": round(kt[c][0], 3), "launches": kt[c][1]} for c, name in
+                          enumerate(["closest", "shadow", "generate", "shade", "accumulate"])},
+        }
+
+        # ---- CPU oracle: work per ray in reference visit order, and (N=1) the CPU baseline ----
+        roof = None
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import orc
+            threads = args.cpu_threads or host_threads(1)
+            tb = time.time()
+            oscene = orc.Scene(tris, threads=threads)
+            t_oracle_build = time.time() - tb
+            ocam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+            # bounded sample: every 4th row-band of the same frame, 1 spp (a quarter of a pass)
+            bands = [(0, y, W, min(8, H - y)) for y in range(0, H, 32)]
+            work = np.zeros(6, dtype=np.uint64)
+            rgb = np.zeros((H, W, 3), np.float32)
+            pas = np.zeros((H, W), np.int32)
+            for b in bands:
+                _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, b, 0, 1, seed=args.seed, threads=threads,
+                                        rgb=rgb, passes=pas, count_work=True)
+                work += c
+            n_box_c, n_tri_c = work[2] / work[0], work[3] / work[0]
+            n_box_s, n_tri_s = work[4] / max(work[1], 1), work[5] / max(work[1], 1)
+            b_closest = n_box_c * 32 + n_tri_c * 36 + 24 + 16
+            b_shadow = n_box_s * 32 + n_tri_s * 36 + 24 + 1
+            if world == 1:
+                tb = time.time()
+                rgb[:] = 0
+                pas[:] = 0
+                cnt = np.zeros(2, dtype=np.uint64)
+                for b in bands:
+                    _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, b, 0, 1, seed=args.seed, threads=threads,
+                                            rgb=rgb, passes=pas)
+                    cnt += c
+                t_cpu = time.time() - tb
+                n_samp = int(pas.sum())
+                cpu = {"value": round(float(cnt.sum()) / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+                       "kind": "port",
+                       "sample": "CPU oracle (strict-IEEE restatement of the reference path), %d threads, every 4th "
+                                 "8-row band of the same %dx%d frame at 1 spp = %d camera samples in %.2f s; "
+                                 "extrapolates to %.0f s per 1000 spp" % (threads, W, H, n_samp, t_cpu,
+                                                                          t_cpu / n_samp * W * H * 1000),
+                       "camera_samples_per_s": round(n_samp / t_cpu, 1),
+                       "oracle_scene_build_s": round(t_oracle_build, 2)}
+            ms_c, launches_c = kt[0]
+            if ms_c > 0 and launches_c > 0:
+                bytes_per_launch = closest / launches_c * b_closest   # rank 0's own launches
+                achieved = bytes_per_launch / (ms_c / launches_c * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "k_trace<closest>",
+                        "algorithmic_bytes_per_ray": round(float(b_closest), 1),
+                        "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
+                        "rays_per_launch": round(closest / launches_c, 1),
+                        "avg_launch_ms": round(ms_c / launches_c, 4),
+                        "shadow_kernel": {"algorithmic_bytes_per_ray": round(float(b_shadow), 1),
+                                          "box_tests_per_ray": round(float(n_box_s), 3),
+                                          "tri_tests_per_ray": round(float(n_tri_s), 3),
+                                          "achieved": round(shadow / max(kt[1][1], 1) * b_shadow /
+                                                            (kt[1][0] / max(kt[1][1], 1) * 1e-3) / 1e9, 2) if kt[1][0] > 0 else None}}
+        out["roofline"] = roof
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

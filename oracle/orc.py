@@ -61,6 +61,7 @@ def lib():
         L.orc_shadow_visible.argtypes = [vp, i64, vp, vp, vp, vp, i32]
         L.orc_camera_rays.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, u32, u64, vp, vp]
         L.orc_render.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, u32, u32, u64, vp, vp, vp, i32]
+        L.orc_render_counting.argtypes = L.orc_render.argtypes
         L.orc_tonemap.argtypes = [vp, vp, i64, C.c_float, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_uniform01.restype = C.c_double
@@ -180,15 +181,19 @@ class Scene:
         return vis
 
     def render(self, cam, lights, width, height, rect=None, first_sample=0, n_samples=1, seed=1, threads=8,
-               rgb=None, passes=None):
+               rgb=None, passes=None, count_work=False):
+        """Returns (rgb_sum, passes, counts).  counts = [closest casts, shadow casts] or, with
+        count_work, additionally [closest box tests, closest triangle tests, shadow box tests,
+        shadow triangle tests]."""
         x0, y0, w, h = rect if rect is not None else (0, 0, -1, -1)
         if rgb is None:
             rgb = np.zeros((height, width, 3), dtype=np.float32)
         if passes is None:
             passes = np.zeros((height, width), dtype=np.int32)
-        counts = np.zeros(2, dtype=np.uint64)
+        counts = np.zeros(6 if count_work else 2, dtype=np.uint64)
         larr = make_lights(lights)
-        lib().orc_render(self.h, C.byref(cam), larr, len(lights), width, height, x0, y0, w, h, first_sample,
+        fn = lib().orc_render_counting if count_work else lib().orc_render
+        fn(self.h, C.byref(cam), larr, len(lights), width, height, x0, y0, w, h, first_sample,
                          n_samples, seed, _p(rgb), _p(passes), _p(counts), threads)
         return rgb, passes, counts
 

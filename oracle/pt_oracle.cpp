@@ -532,10 +532,13 @@ struct PathCtx {
     uint64_t seed;
     uint32_t pixel, sample;
     uint64_t closest_casts, shadow_casts;
+    Counters* work_closest; /* optional: box/triangle tests spent on closest-hit casts */
+    Counters* work_shadow;  /* ... and on shadow casts */
 };
 
-inline bool scene_ray_test(const Scene* s, const Ray& ray, Hit& h) {
+inline bool scene_ray_test(const Scene* s, const Ray& ray, Hit& h, Counters* cn = nullptr) {
     CastingRay c = make_casting(ray); /* kdtree.cpp:577-580: implicit Ray -> CastingRay */
+    if (cn) return node_ray_test<true>(s->root, s->mesh, c, h, cn);
     return node_ray_test<false>(s->root, s->mesh, c, h, nullptr);
 }
 
@@ -543,7 +546,7 @@ inline bool scene_ray_test(const Scene* s, const Ray& ray, Hit& h) {
 V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
     Hit h;
     ctx.closest_casts++;
-    bool result = scene_ray_test(ctx.scene, ray, h);
+    bool result = scene_ray_test(ctx.scene, ray, h, ctx.work_closest);
     V3 energy = mk(0, 0, 0);
     if (!result) return ctx.sky; /* :153 */
     const Tri& tr = ctx.scene->mesh[h.idx];
@@ -570,7 +573,7 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
         Ray shadow = make_ray(hit, to_light);
         Hit sh;
         ctx.shadow_casts++;
-        bool shadow_result = scene_ray_test(ctx.scene, shadow, sh);
+        bool shadow_result = scene_ray_test(ctx.scene, shadow, sh, ctx.work_shadow);
         float dist = norm(to_light);
         /* :127 passes (ignore_u, ignore_v, shadow_param) where (t, u, v) are expected, so the
          * value compared with the light distance is the barycentric v of the closest hit. */
@@ -760,9 +763,9 @@ void orc_camera_rays(const orc_camera* cam, int width, int height, int x0, int y
         }
 }
 
-void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
-                int height, int x0, int y0, int w, int h, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
-                float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads) {
+static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
+                        int height, int x0, int y0, int w, int h, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
+                        float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads, bool count_work) {
     if (n_lights > MAX_LIGHTS) n_lights = MAX_LIGHTS;
     /* PassDescriptor::clamp_bounds, integrator.cpp:164-183 */
     if (x0 < 0) x0 = 0;
@@ -774,8 +777,8 @@ void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* ligh
     if (w > width - x0) w = width - x0;
     if (h > height - y0) h = height - y0;
     CameraBasis basis = camera_basis(*cam, width, height);
-    std::vector<uint64_t> counts((size_t)(threads < 1 ? 1 : threads) * 2, 0);
     int nthreads = threads < 1 ? 1 : threads;
+    std::vector<uint64_t> counts((size_t)nthreads * 6, 0);
     /* Rows are dealt round-robin in blocks so threads finish together. */
     std::vector<std::thread> pool;
     auto work = [&](int tid) {
@@ -783,6 +786,9 @@ void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* ligh
         ctx.scene = &s->s; ctx.lights = lights; ctx.n_lights = n_lights;
         ctx.sky = mk(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
         ctx.seed = seed; ctx.closest_casts = 0; ctx.shadow_casts = 0;
+        Counters wc, ws;
+        ctx.work_closest = count_work ? &wc : nullptr;
+        ctx.work_shadow = count_work ? &ws : nullptr;
         for (int y = y0 + tid; y < y0 + h; y += nthreads)
             for (int x = x0; x < x0 + w; x++) {
                 int pix = y * width + x;
@@ -796,8 +802,9 @@ void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* ligh
                     passes[pix] += 1;                         /* :265 */
                 }
             }
-        counts[2 * tid] = ctx.closest_casts;
-        counts[2 * tid + 1] = ctx.shadow_casts;
+        uint64_t* c = &counts[6 * (size_t)tid];
+        c[0] = ctx.closest_casts; c[1] = ctx.shadow_casts;
+        c[2] = wc.box; c[3] = wc.tri; c[4] = ws.box; c[5] = ws.tri;
     };
     if (nthreads == 1) work(0);
     else {
@@ -805,7 +812,22 @@ void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* ligh
         for (auto& th : pool) th.join();
     }
     if (ray_counts)
-        for (int t = 0; t < nthreads; t++) { ray_counts[0] += counts[2 * t]; ray_counts[1] += counts[2 * t + 1]; }
+        for (int t = 0; t < nthreads; t++)
+            for (int k = 0; k < (count_work ? 6 : 2); k++) ray_counts[k] += counts[6 * (size_t)t + k];
+}
+
+void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
+                int height, int x0, int y0, int w, int h, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
+                float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads) {
+    render_impl(s, cam, lights, n_lights, width, height, x0, y0, w, h, first_sample, n_samples, seed, rgb_sum, passes,
+                ray_counts, threads, false);
+}
+
+void orc_render_counting(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
+                         int height, int x0, int y0, int w, int h, uint32_t first_sample, uint32_t n_samples,
+                         uint64_t seed, float* rgb_sum, int32_t* passes, uint64_t* work_counts, int threads) {
+    render_impl(s, cam, lights, n_lights, width, height, x0, y0, w, h, first_sample, n_samples, seed, rgb_sum, passes,
+                work_counts, threads, true);
 }
 
 /* canvas.cpp:39-45 */

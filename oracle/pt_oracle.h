@@ -96,6 +96,14 @@ void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* ligh
                 uint32_t first_sample, uint32_t n_samples, uint64_t seed,
                 float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads);
 
+/* Same render, additionally counting the work of the reference's tree walk: work_counts[0..5] +=
+ * closest casts, shadow casts, box tests and triangle tests of the closest casts, box tests
+ * and triangle tests of the shadow casts (reference visit order, no extra pruning). */
+void orc_render_counting(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights,
+                         int width, int height, int x0, int y0, int w, int h,
+                         uint32_t first_sample, uint32_t n_samples, uint64_t seed,
+                         float* rgb_sum, int32_t* passes, uint64_t* work_counts, int threads);
+
 /* Canvas::get_pixel for a whole image (canvas.cpp:39-45): rgb8 = W*H*3 bytes. */
 void orc_tonemap(const float* rgb_sum, const int32_t* passes, int64_t n_pixels, float gain,
                  uint8_t* rgb8);
