@@ -69,8 +69,11 @@ struct RaySoAW {
 };
 
 #define TRACE_BLOCK 256
-#define STACK_CLOSEST (3 * PT_MAX_TREE_DEPTH)
-#define STACK_ANYHIT (PT_MAX_TREE_DEPTH)
+#define STACK_MAX_CLOSEST (3 * PT_MAX_TREE_DEPTH) /* worst case of the closest-hit walk */
+#define STACK_MAX_ANYHIT (PT_MAX_TREE_DEPTH)
+#define STACK_LDS 16       /* dwords per lane kept in LDS; deeper entries spill to HBM (rare: <1 % of rays) */
+#define TRACE_CHUNK 256    /* rays a wave takes from the queue per atomic */
+#define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
 
 struct GpuMem {
     const float4* nodes;
@@ -94,14 +97,23 @@ struct GpuMem {
     }
 };
 
-/* Per-lane stack in LDS, dword-interleaved across the block: entry i of thread t lives at
- * word i*TRACE_BLOCK + t, so whatever the lanes' depths are, a wave's 64 accesses fall in 64
- * different words of two bank rows and never conflict. */
-struct LdsStack {
-    uint32_t* base;
-    int sp;
-    __device__ __forceinline__ void push(uint32_t v) { base[sp * TRACE_BLOCK] = v; sp++; }
-    __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * TRACE_BLOCK]; }
+/* Per-lane stack.  The first STACK_LDS entries live in LDS, dword-interleaved across the block
+ * (entry i of thread t at word i*TRACE_BLOCK + t), so whatever the lanes' depths are, a wave's
+ * 64 accesses fall in 64 different banks.  Deeper entries go to a per-thread column of a spill
+ * buffer in HBM, interleaved the same way across the whole grid. */
+struct LaneStack {
+    uint32_t* lds;    /* &stk[threadIdx.x] */
+    uint32_t* spill;  /* &spill[global thread id] */
+    uint32_t stride;  /* threads in the grid */
+    __device__ __forceinline__ void push(int& sp, uint32_t v) {
+        if (sp < STACK_LDS) lds[sp * TRACE_BLOCK] = v;
+        else spill[(size_t)(sp - STACK_LDS) * stride] = v;
+        sp++;
+    }
+    __device__ __forceinline__ uint32_t pop(int& sp) {
+        sp--;
+        return sp < STACK_LDS ? lds[sp * TRACE_BLOCK] : spill[(size_t)(sp - STACK_LDS) * stride];
+    }
 };
 
 /* ----------------------------------------------------------------- tracing */
@@ -109,68 +121,144 @@ struct LdsStack {
 enum TraceMode {
     TRACE_CLOSEST_MESH = 0, /* outputs mesh index, t, u, v              (pt_raycast_closest) */
     TRACE_CLOSEST_FLAT = 1, /* outputs leaf-order position, t, u, v     (renderer)           */
-    TRACE_SHADOW_ANY = 2,   /* visibility for dist >= 1; marks others 2 (see k_trace)        */
-    TRACE_SHADOW_EXACT = 3  /* visibility for the rays marked 2: closest hit, v > dist       */
+    TRACE_SHADOW_ANY = 2,   /* visibility for dist >= 1; queues the others for the exact pass */
+    TRACE_SHADOW_EXACT = 3  /* visibility for the queued rays: closest hit, v > dist          */
 };
 
 struct TraceArgs {
     RaySoA rays;
-    const uint32_t* d_count; /* number of rays, in device memory */
+    const uint32_t* d_count; /* number of work items, in device memory */
     uint32_t* d_next_chunk;  /* atomic chunk counter, zero at launch */
     int32_t* out_idx;
     float *out_t, *out_u, *out_v;
     const float* dist;       /* shadow modes */
     uint8_t* vis;            /* shadow modes */
+    uint32_t* defer_list;    /* SHADOW_ANY appends ray indices here, SHADOW_EXACT reads them */
+    uint32_t* defer_count;   /* SHADOW_ANY: atomic length of defer_list (zero at launch) */
+    uint32_t* spill;         /* stack spill area: (STACK_MAX - STACK_LDS) * threads-in-grid dwords */
 };
 
+/*
+ * Persistent trace kernel.  Every wave loops over "rounds"; in a round each lane that holds a
+ * ray advances it by one step of the lane state machine (traverse_core.h): either one triangle
+ * of its pending leaf, or stack pops followed by one interior node.  The loads of a round
+ * (triangle records, node records, and the rays of lanes being refilled) are issued before
+ * any of them is consumed, so a round costs one memory round trip.  Lanes whose ray is
+ * finished write their result and go idle; when enough lanes are idle the wave hands them the
+ * next rays of its chunk (TRACE_CHUNK consecutive rays, one atomic on the queue head per chunk).
+ * The loop ends when the queue is empty and every lane is idle, so the grid always drains.
+ */
 template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY);
-    constexpr int CAP = ANY ? STACK_ANYHIT : STACK_CLOSEST;
-    __shared__ uint32_t stk[CAP * TRACE_BLOCK];
+    constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
+    __shared__ uint32_t stk[STACK_LDS * TRACE_BLOCK];
     const uint32_t n = *a.d_count;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     GpuMem mem;
     mem.nodes = sc.nodes; mem.tris = sc.tris;
+    LaneStack st;
+    st.lds = stk + threadIdx.x;
+    st.stride = gridDim.x * TRACE_BLOCK;
+    st.spill = a.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
+
+    Lane L;
+    L.cur = PT_REF_NONE; L.leaf_pos = L.leaf_end = 0; L.sp = 0; L.found = false; L.frame_bits = 0;
+    int32_t ray = -1;         /* index of the ray this lane is tracing, or -1 (idle) */
+    float dist = 0.0f;
+    uint32_t pool_next = 0, pool_end = 0; /* wave-uniform: unclaimed rays of the current chunk */
+    bool exhausted = false;               /* wave-uniform: the queue has no more chunks */
+
     while (true) {
-        /* one atomic per wave: the next 64 consecutive rays */
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(a.d_next_chunk, 1u);
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
-        uint64_t first = (uint64_t)chunk * 64u;
-        if (first >= n) break;
-        uint32_t i = (uint32_t)first + lane;
-        if (i < n) {
-            bool skip = false;
-            float dist = 0.0f;
-            if (MODE == TRACE_SHADOW_ANY) {
-                dist = a.dist[i];
-                /* Every hit has v <= 1, so with dist >= 1 the reference's test `v > dist` fails for
-                 * any hit and the answer is hit/no-hit.  Nearer lights need the closest hit's v. */
-                if (!(dist >= 1.0f)) { a.vis[i] = 2; skip = true; }
-            }
-            if (MODE == TRACE_SHADOW_EXACT) {
-                if (a.vis[i] != 2) skip = true; else dist = a.dist[i];
-            }
-            if (!skip) {
-                Ray9 r;
-                r.ox = a.rays.ox[i]; r.oy = a.rays.oy[i]; r.oz = a.rays.oz[i];
-                r.dx = a.rays.dx[i]; r.dy = a.rays.dy[i]; r.dz = a.rays.dz[i];
-                ray_set_recip(r);
-                LdsStack st;
-                st.base = stk + threadIdx.x; st.sp = 0;
-                Hit h;
-                bool found = trace_lane<ANY>(mem, sc.root_ref, sc.root, r, st, h);
-                if (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) {
-                    a.out_idx[i] = found ? (int32_t)(MODE == TRACE_CLOSEST_MESH ? h.mesh : h.tri) : -1;
-                    a.out_t[i] = found ? h.t : 0.0f;
-                    a.out_u[i] = found ? h.u : 0.0f;
-                    a.out_v[i] = found ? h.v : 0.0f;
-                } else if (MODE == TRACE_SHADOW_ANY) {
-                    a.vis[i] = found ? 0 : 1;
-                } else {
-                    a.vis[i] = (!found || h.v > dist) ? 1 : 0;
+        /* ---- refill idle lanes ---- */
+        const uint64_t idle = __ballot(ray < 0);
+        bool starting = false;
+        uint32_t new_ray = 0;
+        if (idle) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
+                if (pool_next >= pool_end) {
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(a.d_next_chunk, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    uint64_t first = (uint64_t)c * TRACE_CHUNK;
+                    if (first >= n) exhausted = true;
+                    else { pool_next = (uint32_t)first; pool_end = (uint32_t)min((uint64_t)n, first + TRACE_CHUNK); }
                 }
+                if (!exhausted) {
+                    uint32_t k = pool_next + (uint32_t)__popcll(idle & lt_mask);
+                    starting = (ray < 0) && (k < pool_end);
+                    new_ray = k;
+                    pool_next = min(pool_end, pool_next + n_idle);
+                }
+            }
+            if (exhausted && idle == ~0ull) break;
+        }
+        Ray9 nr;
+        float ndist = 0.0f;
+        if (starting) {
+            if (MODE == TRACE_SHADOW_EXACT) new_ray = a.defer_list[new_ray];
+            if (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_EXACT) ndist = a.dist[new_ray];
+            nr.ox = a.rays.ox[new_ray]; nr.oy = a.rays.oy[new_ray]; nr.oz = a.rays.oz[new_ray];
+            nr.dx = a.rays.dx[new_ray]; nr.dy = a.rays.dy[new_ray]; nr.dz = a.rays.dz[new_ray];
+        }
+
+        /* ---- this round's loads: triangle records first, then (after the pops) node records ---- */
+        const bool active = ray >= 0;
+        const bool do_tri = active && lane_has_leaf(L);
+        TriData tr;
+        if (do_tri) mem.load_tri(L.leaf_pos, tr);
+        if (active && !do_tri && !lane_has_node(L) && L.sp > 0) {
+            lane_pop<ANY>(L, st);
+            if (!lane_has_node(L) && !lane_has_leaf(L) && L.sp > 0) lane_pop<ANY>(L, st);
+        }
+        const bool do_node = active && !do_tri && lane_has_node(L);
+        NodeData nd;
+        if (do_node) mem.load_node(L.cur, nd);
+
+        /* ---- one step per lane ---- */
+        if (do_tri) lane_tri<ANY>(L, tr);
+        if (do_node) lane_node<ANY>(L, nd, st);
+
+        /* ---- retire finished rays ---- */
+        if (active && lane_finished(L)) {
+            const uint32_t i = (uint32_t)ray;
+            if (CLOSEST_OUT) {
+                a.out_idx[i] = L.found ? (int32_t)(MODE == TRACE_CLOSEST_MESH ? L.best.mesh : L.best.tri) : -1;
+                a.out_t[i] = L.found ? L.best.t : 0.0f;
+                a.out_u[i] = L.found ? L.best.u : 0.0f;
+                a.out_v[i] = L.found ? L.best.v : 0.0f;
+            } else if (MODE == TRACE_SHADOW_ANY) {
+                a.vis[i] = L.found ? 0 : 1;
+            } else {
+                a.vis[i] = (!L.found || L.best.v > dist) ? 1 : 0;
+            }
+            ray = -1;
+        }
+
+        /* ---- start the refilled lanes (their loads were issued at the top of the round) ---- */
+        bool defer = false;
+        if (starting) {
+            /* Every hit has v <= 1, so with dist >= 1 the reference's test `v > dist` fails for any
+             * hit and the answer is hit/no-hit.  Nearer lights need the closest hit's v: those rays
+             * are queued for the exact pass. */
+            if (MODE == TRACE_SHADOW_ANY && !(ndist >= 1.0f)) defer = true;
+            else {
+                L.r = nr;
+                ray_set_recip(L.r);
+                lane_start(L, sc.root_ref, sc.root);
+                ray = (int32_t)new_ray;
+                dist = ndist;
+            }
+        }
+        if (MODE == TRACE_SHADOW_ANY) {
+            const uint64_t dm = __ballot(defer);
+            if (dm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.defer_count, (uint32_t)__popcll(dm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (defer) a.defer_list[base + (uint32_t)__popcll(dm & lt_mask)] = new_ray;
             }
         }
     }
@@ -205,9 +293,11 @@ struct RenderBuffers {
     RaySoAW sh;
     float *sh_dist, *sh_wr, *sh_wg, *sh_wb;
     uint8_t* sh_vis;
+    uint32_t* sh_defer;
     /* counters: [0..11] queue length per depth, [12..23] trace chunk counters (closest),
      * [24..35] shadow-ray count per depth, [36..47] chunk counters (shadow any),
-     * [48..59] chunk counters (shadow exact), [60] camera samples */
+     * [48..59] chunk counters (shadow exact), [60] camera samples,
+     * [64..75] shadow rays per depth that need the exact pass */
     uint32_t* cnt;
 };
 #define CNT_QUEUE 0
@@ -216,7 +306,8 @@ struct RenderBuffers {
 #define CNT_CHUNK_ANY 36
 #define CNT_CHUNK_EXACT 48
 #define CNT_SAMPLES 60
-#define CNT_WORDS 64
+#define CNT_DEFER 64
+#define CNT_WORDS 80
 
 __device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_sp, uint32_t p) {
     uint32_t lo = 0, hi = n_sp;
@@ -410,13 +501,19 @@ struct pt_scene {
     void* d_tris = nullptr;
     void* d_shade = nullptr;
     uint64_t n_tris = 0;
-    uint32_t* d_small = nullptr; /* [0] ray count, [1..3] chunk counters for the raycast entry points */
+    uint32_t* d_small = nullptr; /* [0] ray count, [1..2] chunk counters, [3] deferred count (raycast entry points) */
+    uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
+    uint32_t* d_defer = nullptr; /* deferred shadow rays of pt_raycast_shadow_dev */
+    uint64_t defer_cap = 0;
+    int grid_closest = 0, grid_any = 0; /* resident blocks of the persistent trace kernels */
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
     double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
     uint64_t launches[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
     bool timing = true;
 };
+
+static int init_trace_launch(pt_scene* s);
 
 static int set_device(const pt_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
@@ -543,6 +640,7 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     s->d.shade = (const float4*)s->d_shade;
     s->d.root_ref = flat->root_ref;
     s->d.n_tris = (uint32_t)flat->n_tris;
+    if (init_trace_launch(s) != PT_OK) return cleanup(PT_ERR_DEVICE);
     s->d.root.mnx = flat->root_min[0]; s->d.root.mny = flat->root_min[1]; s->d.root.mnz = flat->root_min[2];
     s->d.root.mxx = flat->root_max[0]; s->d.root.mxy = flat->root_max[1]; s->d.root.mxz = flat->root_max[2];
     *out = s;
@@ -559,6 +657,8 @@ void pt_scene_destroy(pt_scene* s) {
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_small) (void)hipFree(s->d_small);
+    if (s->d_spill) (void)hipFree(s->d_spill);
+    if (s->d_defer) (void)hipFree(s->d_defer);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -585,18 +685,34 @@ int pt_scene_kernel_time(pt_scene* s, int cls, int reset, double* ms, uint64_t* 
 
 } // extern "C"
 
-/* Grid of a persistent trace launch: as many blocks as stay resident (LDS-limited). */
-static int trace_grid(const pt_scene* s, bool anyhit) {
-    int per_cu = anyhit ? 6 : 2;
-    return s->num_cus * per_cu;
-}
+/* Grid of a persistent trace launch: as many blocks as stay resident, so every wave starts at
+ * once and pulls work until the queue is empty. */
+static int trace_grid(const pt_scene* s, bool anyhit) { return anyhit ? s->grid_any : s->grid_closest; }
 
 template <int MODE>
-static int launch_trace(pt_scene* s, const TraceArgs& a) {
+static int launch_trace(pt_scene* s, TraceArgs a) {
     if (s->pending.size() > 8192) { int rc = resolve_timing(s); if (rc) return rc; }
+    a.spill = s->d_spill;
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW);
     hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY)), dim3(TRACE_BLOCK), 0, s->stream, s->d, a);
     HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+/* Sizes the persistent grids from the occupancy the compiled kernels actually get and
+ * allocates the stack spill area for the larger of them. */
+static int init_trace_launch(pt_scene* s) {
+    int per_cu_c = 0, per_cu_a = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT>, TRACE_BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY>, TRACE_BLOCK, 0));
+    if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) { per_cu_c = v; per_cu_a = v; } }
+    per_cu_c = std::max(1, std::min(per_cu_c, 8));
+    per_cu_a = std::max(1, std::min(per_cu_a, 8));
+    s->grid_closest = s->num_cus * per_cu_c;
+    s->grid_any = s->num_cus * per_cu_a;
+    size_t threads = (size_t)std::max(s->grid_closest, s->grid_any) * TRACE_BLOCK;
+    size_t words = threads * (size_t)(STACK_MAX_CLOSEST - STACK_LDS);
+    HIP_TRY(hipMalloc((void**)&s->d_spill, words * sizeof(uint32_t)));
     return PT_OK;
 }
 
@@ -637,15 +753,23 @@ int pt_raycast_shadow_dev(pt_scene* s, uint64_t n, const float* ox, const float*
     int rc = set_device(s);
     if (rc) return rc;
     if (s->n_tris == 0) { HIP_TRY(hipMemsetAsync(vis, 1, n, s->stream)); return PT_OK; }
-    uint32_t init[3] = {(uint32_t)n, 0u, 0u};
+    if (n > s->defer_cap) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->d_defer) (void)hipFree(s->d_defer);
+        s->d_defer = nullptr; s->defer_cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_defer, n * sizeof(uint32_t)));
+        s->defer_cap = n;
+    }
+    uint32_t init[4] = {(uint32_t)n, 0u, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
     TraceArgs a{};
     a.rays = {ox, oy, oz, dx, dy, dz};
     a.d_count = s->d_small; a.d_next_chunk = s->d_small + 1;
     a.dist = dist; a.vis = vis;
+    a.defer_list = s->d_defer; a.defer_count = s->d_small + 3;
     rc = launch_trace<TRACE_SHADOW_ANY>(s, a);
     if (rc) return rc;
-    a.d_next_chunk = s->d_small + 2;
+    a.d_count = s->d_small + 3; a.d_next_chunk = s->d_small + 2;
     return launch_trace<TRACE_SHADOW_EXACT>(s, a);
 }
 
@@ -770,6 +894,7 @@ static int film_ensure_scratch(pt_film* f, size_t paths, uint32_t n_lights, size
     float** per_sh[11] = {&b.sh.ox, &b.sh.oy, &b.sh.oz, &b.sh.dx, &b.sh.dy, &b.sh.dz, &b.sh_dist, &b.sh_wr, &b.sh_wg, &b.sh_wb, nullptr};
     for (int c = 0; per_sh[c] && !rc; c++) rc = film_alloc(f, per_sh[c], S);
     if (!rc) rc = film_alloc(f, &b.sh_vis, S);
+    if (!rc) rc = film_alloc(f, &b.sh_defer, S);
     if (!rc) rc = film_alloc(f, &b.cnt, (size_t)CNT_WORDS);
     if (!rc) rc = film_alloc(f, &f->d_lights, (size_t)PT_MAX_LIGHTS);
     if (!rc) rc = film_alloc(f, &f->d_sub, G);
@@ -834,8 +959,10 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
             sa.d_count = b.cnt + CNT_SHADOW + depth;
             sa.d_next_chunk = b.cnt + CNT_CHUNK_ANY + depth;
             sa.dist = b.sh_dist; sa.vis = b.sh_vis;
+            sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
             rc = launch_trace<TRACE_SHADOW_ANY>(s, sa);
             if (rc) return rc;
+            sa.d_count = b.cnt + CNT_DEFER + depth;
             sa.d_next_chunk = b.cnt + CNT_CHUNK_EXACT + depth;
             rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa);
             if (rc) return rc;

@@ -176,88 +176,138 @@ PT_HD uint32_t ref_leaf_start(uint32_t ref) { return ref & PT_REF_START_MASK; }
 PT_HD uint32_t ref_leaf_count(uint32_t ref) { return (ref >> PT_REF_COUNT_SHIFT) & PT_REF_COUNT_MASK; }
 
 /*
- * Closest hit, one lane.  Reproduces the recursion of kdTreeNode::ray_test with an explicit
- * stack.  The recursion combines sub-results with strict '<' and "first visited wins ties";
- * that is the minimum over (t, visit order) of all triangle hits in visited leaves, so a
- * single running `best` updated with strict '<' in visit order gives the same answer.  The
- * one place where a SUB-result matters is the far-side test `hit_parameter > t_far`
- * (:367), which uses the near subtree's own closest t.  `local` tracks the closest t found
- * since the innermost pending far-side frame was pushed; a frame saves the enclosing value
- * and restores min(saved, local) when popped.
+ * Closest hit, one lane, as a state machine.  Reproduces the recursion of
+ * kdTreeNode::ray_test with an explicit stack.  The recursion combines sub-results with strict
+ * '<' and "first visited wins ties"; that is the minimum over (t, visit order) of all triangle
+ * hits in visited leaves, so a single running `best` updated with strict '<' in visit order
+ * gives the same answer.  The one place where a SUB-result matters is the far-side test
+ * `hit_parameter > t_far` (:367), which uses the near subtree's own closest t.  `local` tracks
+ * the closest t found since the innermost pending far-side frame was pushed; a frame saves the
+ * enclosing value and restores min(saved, local) when popped.
  *
- * Stack entries: a plain child reference (1 dword), or a frame of 3 dwords pushed as
- * {saved local, t_far, far_ref | PT_REF_FRAME}.  At most one entry group per interior
- * ancestor is pending, so 3 * PT_MAX_TREE_DEPTH dwords suffice.
+ * Stack entries, pushed in this order:
+ *   plain child reference                         1 dword  (the "overlaps both" case)
+ *   frame {[saved local], t_far, far_ref|FRAME}   2 or 3 dwords
+ * The saved value is +inf until the enclosing scope has found a hit, which is the common case;
+ * it is then not stored, and one bit per pending frame (`frame_bits`, a bit stack: frames nest
+ * at most PT_MAX_TREE_DEPTH deep) records whether it was.  At most one entry group per interior
+ * ancestor is pending, so 3 * PT_MAX_TREE_DEPTH dwords always suffice.
  *
  * ANYHIT: stop at the first triangle hit; the result is only hit/no-hit.  The far side is then
  * visited iff the near side found nothing, which needs no frame (a plain deferred reference
  * does it), so 1 * PT_MAX_TREE_DEPTH dwords suffice.
  *
- * Mem supplies load_node(index, NodeData&) and load_tri(position, TriData&).
- * Stack supplies push(uint32_t) and pop() and is private to the lane.
+ * A lane is always in exactly one of these situations:
+ *   leaf pending   (leaf_pos != leaf_end)  -> lane_tri() with the triangle at leaf_pos
+ *   interior node  (cur != NONE)           -> lane_node() with that node
+ *   neither, stack not empty               -> lane_pop()
+ *   neither, stack empty                   -> finished
+ * Stack supplies push(int& sp, uint32_t) and pop(int& sp), which move the lane's stack pointer,
+ * and is private to the lane.
  */
+struct Lane {
+    Ray9 r;
+    Hit best;
+    float local;
+    uint32_t cur;                /* interior node to visit, or PT_REF_NONE */
+    uint32_t leaf_pos, leaf_end; /* pending leaf triangles; leaf_end == PT_LEAF_UNKNOWN until the
+                                    first record of an oversized leaf has been read */
+    uint32_t frame_bits;
+    int sp;
+    bool found;
+};
+#define PT_LEAF_UNKNOWN 0xffffffffu
+
+PT_HD bool lane_has_leaf(const Lane& L) { return L.leaf_pos != L.leaf_end; }
+PT_HD bool lane_has_node(const Lane& L) { return L.cur != PT_REF_NONE; }
+PT_HD bool lane_finished(const Lane& L) { return !lane_has_leaf(L) && !lane_has_node(L) && L.sp == 0; }
+
+/* Routes a child reference: interior nodes go to `cur`, leaves become the pending leaf. */
+PT_HD void lane_enter(Lane& L, uint32_t ref) {
+    if (ref != PT_REF_NONE && ref_is_leaf(ref)) {
+        uint32_t start = ref_leaf_start(ref), count = ref_leaf_count(ref);
+        L.leaf_pos = start;
+        L.leaf_end = count ? start + count : PT_LEAF_UNKNOWN;
+        L.cur = PT_REF_NONE;
+    } else {
+        L.cur = ref;
+    }
+}
+
+PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root) {
+    const float inf = pt_inf();
+    L.best.t = inf; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0xffffffffu; L.best.mesh = 0xffffffffu;
+    L.local = inf;
+    L.leaf_pos = 0; L.leaf_end = 0;
+    L.frame_bits = 0; L.sp = 0; L.found = false;
+    lane_enter(L, box_hit(root.mnx, root.mny, root.mnz, root.mxx, root.mxy, root.mxz, L.r) ? root_ref : PT_REF_NONE);
+}
+
+template <bool ANYHIT, class Stack>
+PT_HD void lane_pop(Lane& L, Stack& st) {
+    uint32_t e = st.pop(L.sp);
+    if (!ANYHIT && (e & PT_REF_FRAME)) {
+        const float inf = pt_inf();
+        float t_far = u2f(st.pop(L.sp));
+        float saved = inf;
+        if (L.frame_bits & 1u) saved = u2f(st.pop(L.sp));
+        L.frame_bits >>= 1;
+        float near_local = L.local;
+        /* near side missed (:393-394) or its closest hit lies beyond the far slab (:367) */
+        bool visit = !(near_local < inf) || (near_local > t_far);
+        L.local = saved < near_local ? saved : near_local;
+        lane_enter(L, visit ? (e & ~PT_REF_FRAME) : PT_REF_NONE);
+    } else {
+        lane_enter(L, e);
+    }
+}
+
+template <bool ANYHIT, class Stack>
+PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
+    StepOut o = interior_step(n, L.r);
+    if (o.deferred != PT_REF_NONE) st.push(L.sp, o.deferred);
+    if (o.far != PT_REF_NONE) {
+        if (ANYHIT) st.push(L.sp, o.far);
+        else {
+            const float inf = pt_inf();
+            bool keep = L.local < inf;
+            if (keep) st.push(L.sp, f2u(L.local));
+            L.frame_bits = (L.frame_bits << 1) | (keep ? 1u : 0u);
+            st.push(L.sp, f2u(o.t_far)); st.push(L.sp, o.far | PT_REF_FRAME);
+            L.local = inf;
+        }
+    }
+    lane_enter(L, o.next);
+}
+
+/* One triangle of the pending leaf, in stored order, strict '<' (:281-293). */
+template <bool ANYHIT>
+PT_HD void lane_tri(Lane& L, const TriData& tr) {
+    if (L.leaf_end == PT_LEAF_UNKNOWN) L.leaf_end = L.leaf_pos + tr.leaf_count;
+    float t, u, v;
+    if (tri_hit(tr, L.r, t, u, v)) {
+        if (t < L.best.t) { L.best.t = t; L.best.u = u; L.best.v = v; L.best.tri = L.leaf_pos; L.best.mesh = tr.mesh_index; L.found = true; }
+        if (t < L.local) L.local = t;
+    }
+    L.leaf_pos++;
+    if (ANYHIT && L.found) { L.leaf_pos = L.leaf_end = 0; L.cur = PT_REF_NONE; L.sp = 0; } /* nothing left to do */
+}
+
+/* Runs one lane to completion (the CPU emulation's driver; the kernels interleave the same
+ * steps across the lanes of a wave).  Mem supplies load_node(index, NodeData&) and
+ * load_tri(position, TriData&). */
 template <bool ANYHIT, class Mem, class Stack>
 PT_HD bool trace_lane(const Mem& mem, uint32_t root_ref, const RootBox& root, const Ray9& r, Stack& st, Hit& best) {
-    const float inf = pt_inf();
-    best.t = inf; best.u = 0.0f; best.v = 0.0f; best.tri = 0xffffffffu; best.mesh = 0xffffffffu;
-    bool found = false;
-    float local = inf;
-    int sp = 0;
-    uint32_t cur = box_hit(root.mnx, root.mny, root.mnz, root.mxx, root.mxy, root.mxz, r) ? root_ref : PT_REF_NONE;
-    bool done = false;
-    while (!done) {
-        /* descend until this lane holds a leaf (or has nothing left) */
-        while (!done && !(cur != PT_REF_NONE && ref_is_leaf(cur))) {
-            if (cur == PT_REF_NONE) {
-                if (sp == 0) { done = true; break; }
-                uint32_t e = st.pop(); sp--;
-                if (!ANYHIT && (e & PT_REF_FRAME)) {
-                    float t_far = u2f(st.pop());
-                    float saved = u2f(st.pop());
-                    sp -= 2;
-                    float near_local = local;
-                    /* near side missed (:393-394) or its closest hit lies beyond the far slab (:367) */
-                    bool visit = !(near_local < inf) || (near_local > t_far);
-                    local = saved < near_local ? saved : near_local;
-                    cur = visit ? (e & ~PT_REF_FRAME) : PT_REF_NONE;
-                } else {
-                    cur = e;
-                }
-                continue;
-            }
-            NodeData n;
-            mem.load_node(cur, n);
-            StepOut o = interior_step(n, r);
-            if (o.deferred != PT_REF_NONE) { st.push(o.deferred); sp++; }
-            if (o.far != PT_REF_NONE) {
-                if (ANYHIT) { st.push(o.far); sp++; }
-                else {
-                    st.push(f2u(local)); st.push(f2u(o.t_far)); st.push(o.far | PT_REF_FRAME); sp += 3;
-                    local = inf;
-                }
-            }
-            cur = o.next;
-        }
-        if (done) break;
-        /* leaf: every triangle, in stored order, strict '<' (:281-293) */
-        uint32_t start = ref_leaf_start(cur);
-        uint32_t count = ref_leaf_count(cur);
-        TriData tr;
-        mem.load_tri(start, tr);
-        if (count == 0) count = tr.leaf_count;
-        for (uint32_t k = 0;;) {
-            float t, u, v;
-            if (tri_hit(tr, r, t, u, v)) {
-                if (t < best.t) { best.t = t; best.u = u; best.v = v; best.tri = start + k; best.mesh = tr.mesh_index; found = true; }
-                if (t < local) local = t;
-            }
-            if (++k >= count) break;
-            mem.load_tri(start + k, tr);
-        }
-        cur = PT_REF_NONE;
-        if (ANYHIT && found) done = true;
+    Lane L;
+    L.r = r;
+    lane_start(L, root_ref, root);
+    while (!lane_finished(L)) {
+        if (lane_has_leaf(L)) { TriData tr; mem.load_tri(L.leaf_pos, tr); lane_tri<ANYHIT>(L, tr); }
+        else if (lane_has_node(L)) { NodeData n; mem.load_node(L.cur, n); lane_node<ANYHIT>(L, n, st); }
+        else lane_pop<ANYHIT>(L, st);
     }
-    return found;
+    best = L.best;
+    return L.found;
 }
 
 } // namespace ptc

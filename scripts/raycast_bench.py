@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the trace kernels alone (BASELINE.json configs[1] and an incoherent set).
+
+Rays are resident in HBM; time is the kernels' own (HIP events on the library's stream).
+    python scripts/raycast_bench.py [--level 8] [--reps 5] [--sets primary,bounce,sphere,shadow]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--level", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sets", default="primary,sphere,shadow")
+    ap.add_argument("--check", action="store_true", help="compare a sample of results with the CPU oracle")
+    args = ap.parse_args()
+
+    import torch
+    import path_tracing_amd as pta
+
+    tris = pta.meshgen.standin_scene(args.level)
+    host = pta.HostScene(tris)
+    gpu = pta.GpuScene(host, 0)
+    W, H = args.width, args.height
+    n = W * H
+    dev = "cuda"
+    res = {"triangles": host.n, "tree": host.tree_stats()}
+
+    def soa(a):
+        return [torch.from_numpy(np.ascontiguousarray(a[:, k])).to(dev) for k in range(3)]
+
+    def run_closest(name, rays):
+        m = rays[0].numel()
+        idx = torch.empty(m, dtype=torch.int32, device=dev)
+        t = torch.empty(m, dtype=torch.float32, device=dev)
+        u = torch.empty_like(t)
+        v = torch.empty_like(t)
+        torch.cuda.synchronize()
+        gpu.raycast_closest_dev(rays, idx, t, u, v)
+        gpu.sync()
+        gpu.kernel_time(0, reset=True)
+        for _ in range(args.reps):
+            gpu.raycast_closest_dev(rays, idx, t, u, v)
+        gpu.sync()
+        ms, launches = gpu.kernel_time(0, reset=True)
+        res[name] = {"rays": m, "ms_per_launch": round(ms / launches, 4), "Mrays_s": round(m / (ms / launches) / 1e3, 1),
+                     "hit_fraction": round(float((idx >= 0).float().mean().item()), 4)}
+        return idx, t, u, v
+
+    sets = args.sets.split(",")
+    cam = pta.cli_camera()
+    prim = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(6)]
+    gpu.camera_rays_dev(cam, W, H, (0, 0, W, H), 0, 0, 1, prim)
+    gpu.sync()
+    if "primary" in sets:
+        out = run_closest("primary_rowmajor", prim)
+        if args.check:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import orc
+            osc = orc.Scene(tris, threads=16)
+            sel = np.random.default_rng(0).choice(n, 200000, replace=False)
+            o = np.stack([p.cpu().numpy()[sel] for p in prim[:3]], axis=1)
+            d = np.stack([p.cpu().numpy()[sel] for p in prim[3:]], axis=1)
+            want = osc.raycast(o, d, threads=16)
+            got = [x.cpu().numpy()[sel] for x in out]
+            res["primary_check_bit_exact"] = bool(all(
+                np.array_equal(np.ascontiguousarray(g).view(np.uint32), np.ascontiguousarray(w).view(np.uint32))
+                for g, w in zip(got, want)))
+    if "sphere" in sets:
+        rng = np.random.default_rng(1234)
+        m = 1 << 21
+        o = rng.normal(size=(m, 3))
+        o = 3 * o / np.linalg.norm(o, axis=1, keepdims=True)
+        tt = rng.normal(size=(m, 3))
+        tt = tt / np.linalg.norm(tt, axis=1, keepdims=True) * rng.random((m, 1)) ** (1 / 3)
+        d = (tt - o).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = soa(o.astype(np.float32)) + soa(d.astype(np.float32))
+        run_closest("incoherent_sphere", rays)
+    if "shadow" in sets:
+        # shadow-like rays: from primary hit points toward the first light
+        idx, t, u, v = run_closest("primary_again", prim) if "primary" not in sets else out
+        hit = idx >= 0
+        o = torch.stack([prim[k][hit] + t[hit] * prim[3 + k][hit] for k in range(3)], dim=1)
+        lp = torch.tensor([0.0, 0.0, 3.0], device=dev)
+        d = lp[None, :] - o
+        dist = d.norm(dim=1)
+        d = d / dist[:, None]
+        o = o + 1e-3 * d
+        rays = [o[:, k].contiguous() for k in range(3)] + [d[:, k].contiguous() for k in range(3)]
+        m = rays[0].numel()
+        vis = torch.empty(m, dtype=torch.uint8, device=dev)
+        distc = dist.contiguous()
+        torch.cuda.synchronize()
+        gpu.raycast_shadow_dev(rays, distc, vis)
+        gpu.sync()
+        gpu.kernel_time(1, reset=True)
+        for _ in range(args.reps):
+            gpu.raycast_shadow_dev(rays, distc, vis)
+        gpu.sync()
+        ms, launches = gpu.kernel_time(1, reset=True)
+        res["shadow_to_light0"] = {"rays": m, "ms_per_call": round(ms / args.reps, 4),
+                                   "Mrays_s": round(m / (ms / args.reps) / 1e3, 1),
+                                   "visible_fraction": round(float((vis == 1).float().mean().item()), 4)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,14 +33,14 @@ struct CpuMem {
 
 struct CpuStack {
     uint32_t data[3 * PT_MAX_TREE_DEPTH + 4];
-    int sp = 0, max_sp = 0;
+    int max_sp = 0;
     bool overflow = false;
-    void push(uint32_t v) {
+    void push(int& sp, uint32_t v) {
         if (sp >= (int)(sizeof(data) / sizeof(data[0]))) { overflow = true; return; }
         data[sp++] = v;
         if (sp > max_sp) max_sp = sp;
     }
-    uint32_t pop() { return data[--sp]; }
+    uint32_t pop(int& sp) { return data[--sp]; }
 };
 
 ptc::RootBox root_of(const pt_flat_scene* sc) {
