@@ -401,59 +401,63 @@ inline void philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]
 /* Top 24 bits -> the midpoint of one of 2^24 equal cells of (0,1); exact in double and float. */
 inline double uniform01(uint32_t w) { return ((double)(w >> 8) + 0.5) * (1.0 / 16777216.0); }
 
-/* Natural logarithm for x in (0, 1], from +,-,*,/ only so that every IEEE machine agrees. */
-inline double det_log(double x) {
-    uint64_t bits;
-    memcpy(&bits, &x, 8);
-    int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
-    double m;
-    memcpy(&m, &bits, 8);
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double p = 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+/* ln(y) for a normal binary32 y in (0, 2), from +,-,*,/ only so that every IEEE machine agrees:
+ * y = m * 2^e with m in (sqrt(1/2), sqrt(2)], ln m = 2 atanh((m-1)/(m+1)), odd series to s^9. */
+inline float det_logf(float y) {
+    uint32_t bits;
+    memcpy(&bits, &y, 4);
+    int e = (int)((bits >> 23) & 0xffu) - 127;
+    bits = (bits & 0x007fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &bits, 4);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = 1.0f / 9.0f;
+    p = p * z + 1.0f / 7.0f;
+    p = p * z + 1.0f / 5.0f;
+    p = p * z + 1.0f / 3.0f;
+    p = p * z + 1.0f;
+    return (float)e * 0.693147182f + (2.0f * s) * p;
 }
 
-/* Standard normal by inverse CDF (P. J. Acklam's rational approximation), double arithmetic
- * except one binary32 square root, result narrowed to float. */
-inline float normal_from_uniform(double p) {
-    const double a0 = -3.969683028665376e+01, a1 = 2.209460984245205e+02, a2 = -2.759285104469687e+02,
-                 a3 = 1.383577518672690e+02, a4 = -3.066479806614716e+01, a5 = 2.506628277459239e+00;
-    const double b0 = -5.447609879822406e+01, b1 = 1.615858368580409e+02, b2 = -1.556989798598866e+02,
-                 b3 = 6.680131188771972e+01, b4 = -1.328068155288572e+01;
-    const double c0 = -7.784894002430293e-03, c1 = -3.223964580411365e-01, c2 = -2.400758277161838e+00,
-                 c3 = -2.549732539343734e+00, c4 = 4.374664141464968e+00, c5 = 2.938163982698783e+00;
-    const double d0 = 7.784695709041462e-03, d1 = 3.224671290700398e-01, d2 = 2.445134137142996e+00,
-                 d3 = 3.754408661907416e+00;
-    const double p_low = 0.02425;
-    double x;
-    if (p < p_low) {
-        double q = (double)sqrtf((float)(-2.0 * det_log(p)));
-        x = (((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) / ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0);
-    } else if (p <= 1.0 - p_low) {
-        double q = p - 0.5;
-        double r = q * q;
-        x = (((((a0 * r + a1) * r + a2) * r + a3) * r + a4) * r + a5) * q /
-            (((((b0 * r + b1) * r + b2) * r + b3) * r + b4) * r + 1.0);
+/* Inverse error function in binary32 (M. Giles, "Approximating the erfinv function", 2011). */
+inline float det_erfinvf(float x) {
+    float w = -det_logf((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
     } else {
-        double q = (double)sqrtf((float)(-2.0 * det_log(1.0 - p)));
-        x = -((((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) / ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0));
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
     }
-    return (float)x;
+    return p * x;
+}
+
+/* Standard normal from one random word by inverse CDF: bit 31 is the sign, bits 30..8 pick one
+ * of 2^23 cell midpoints x = (j + 0.5) / 2^23 in (0, 1); the variate is sqrt(2) * erfinv(+-x). */
+inline float normal_from_word(uint32_t w) {
+    float x = ((float)((w >> 8) & 0x7fffffu) + 0.5f) * (1.0f / 8388608.0f);
+    if (w & 0x80000000u) x = -x;
+    return 1.41421354f * det_erfinvf(x);
 }
 
 /* Counter layout: one Philox block per (pixel, sample, stream).
@@ -513,8 +517,8 @@ inline Ray pixel_ray_jittered(const orc_camera& cam, const CameraBasis& b, int W
     V3 offset = b.right * dx + b.up * dy;
     V3 dir = mk(cam.direction[0], cam.direction[1], cam.direction[2]);
     Ray ray = make_ray(mk(cam.origin[0], cam.origin[1], cam.origin[2]), dir + offset);
-    float dof_x = normal_from_uniform(uniform01(w[2])) * cam.dof_dispersion;
-    float dof_y = normal_from_uniform(uniform01(w[3])) * cam.dof_dispersion;
+    float dof_x = normal_from_word(w[2]) * cam.dof_dispersion;
+    float dof_y = normal_from_word(w[3]) * cam.dof_dispersion;
     ray.o = ray.o + dof_x * b.right;
     ray.o = ray.o + dof_y * b.up;
     ray.d = ray.d - (dof_x / cam.plane_of_focus_distance) * b.right;
@@ -565,8 +569,8 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
     for (int l = 0; l < ctx.n_lights; l++) { /* :112-148 */
         uint32_t w[4];
         rng_words(ctx.seed, ctx.pixel, ctx.sample, 16u + 16u * (uint32_t)depth + (uint32_t)l, w);
-        V3 jitter = mk(0.2f * normal_from_uniform(uniform01(w[0])), 0.2f * normal_from_uniform(uniform01(w[1])),
-                       0.2f * normal_from_uniform(uniform01(w[2])));
+        V3 jitter = mk(0.2f * normal_from_word(w[0]), 0.2f * normal_from_word(w[1]),
+                       0.2f * normal_from_word(w[2]));
         V3 lp = mk(ctx.lights[l].position[0], ctx.lights[l].position[1], ctx.lights[l].position[2]);
         V3 lc = mk(ctx.lights[l].color[0], ctx.lights[l].color[1], ctx.lights[l].color[2]);
         V3 to_light = (jitter + lp) - hit;
@@ -843,6 +847,6 @@ void orc_tonemap(const float* rgb_sum, const int32_t* passes, int64_t n_pixels, 
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox(ctr, key, out); }
 double orc_uniform01(uint32_t word) { return uniform01(word); }
-float orc_normal_from_word(uint32_t word) { return normal_from_uniform(uniform01(word)); }
+float orc_normal_from_word(uint32_t word) { return normal_from_word(word); }
 
 } // extern "C"

@@ -71,9 +71,22 @@ struct RaySoAW {
 #define TRACE_BLOCK 256
 #define STACK_MAX_CLOSEST (3 * PT_MAX_TREE_DEPTH) /* worst case of the closest-hit walk */
 #define STACK_MAX_ANYHIT (PT_MAX_TREE_DEPTH)
+#ifndef STACK_LDS
 #define STACK_LDS 16       /* dwords per lane kept in LDS; deeper entries spill to HBM (rare: <1 % of rays) */
-#define TRACE_CHUNK 256    /* rays a wave takes from the queue per atomic */
+#endif
+#ifndef TRACE_CHUNK
+#define TRACE_CHUNK 64     /* rays a wave takes from the queue per atomic */
+#endif
+#ifndef REFILL_MIN
 #define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
+#endif
+#ifndef TRACE_REGIONS
+#define TRACE_REGIONS 1    /* queue regions (one head each), at most 8.  Measured: 8 regions keyed by
+                              XCD (blockIdx % 8 or HW_REG_XCC_ID) were 18-40 % SLOWER than one shared head */
+#endif
+#ifndef TRACE_WAVES_PER_EU
+#define TRACE_WAVES_PER_EU 5 /* register budget of the trace kernels: waves per SIMD the compiler must allow */
+#endif
 
 struct GpuMem {
     const float4* nodes;
@@ -110,9 +123,9 @@ struct LaneStack {
         else spill[(size_t)(sp - STACK_LDS) * stride] = v;
         sp++;
     }
-    __device__ __forceinline__ uint32_t pop(int& sp) {
-        sp--;
-        return sp < STACK_LDS ? lds[sp * TRACE_BLOCK] : spill[(size_t)(sp - STACK_LDS) * stride];
+    __device__ __forceinline__ uint32_t peek(int i) const {
+        i = i < 0 ? 0 : i;
+        return i < STACK_LDS ? lds[i * TRACE_BLOCK] : spill[(size_t)(i - STACK_LDS) * stride];
     }
 };
 
@@ -128,7 +141,7 @@ enum TraceMode {
 struct TraceArgs {
     RaySoA rays;
     const uint32_t* d_count; /* number of work items, in device memory */
-    uint32_t* d_next_chunk;  /* atomic chunk counter, zero at launch */
+    uint32_t* d_next_chunk;  /* 8 atomic chunk counters (one per queue region), zero at launch */
     int32_t* out_idx;
     float *out_t, *out_u, *out_v;
     const float* dist;       /* shadow modes */
@@ -145,11 +158,15 @@ struct TraceArgs {
  * (triangle records, node records, and the rays of lanes being refilled) are issued before
  * any of them is consumed, so a round costs one memory round trip.  Lanes whose ray is
  * finished write their result and go idle; when enough lanes are idle the wave hands them the
- * next rays of its chunk (TRACE_CHUNK consecutive rays, one atomic on the queue head per chunk).
- * The loop ends when the queue is empty and every lane is idle, so the grid always drains.
+ * next rays of its chunk (TRACE_CHUNK consecutive rays, one atomic on a queue head per chunk).
+ * The queue is cut into 8 regions with a head each; a workgroup starts in region blockIdx % 8
+ * (workgroups b and b+8 are observed to share an XCD, hence an L2) and moves on to the next
+ * region when its own is empty, so neighbouring rays tend to meet in one L2 and no region is
+ * left unserved.  The loop ends when every region is empty and every lane is idle, so the
+ * grid always drains.
  */
 template <int MODE>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES_PER_EU))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY);
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
     __shared__ uint32_t stk[STACK_LDS * TRACE_BLOCK];
@@ -164,11 +181,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
     st.spill = a.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
 
     Lane L;
-    L.cur = PT_REF_NONE; L.leaf_pos = L.leaf_end = 0; L.sp = 0; L.found = false; L.frame_bits = 0;
+    L.cur = PT_REF_NONE; L.leaf_pos = L.leaf_end = 0; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
     int32_t ray = -1;         /* index of the ray this lane is tracing, or -1 (idle) */
     float dist = 0.0f;
     uint32_t pool_next = 0, pool_end = 0; /* wave-uniform: unclaimed rays of the current chunk */
     bool exhausted = false;               /* wave-uniform: the queue has no more chunks */
+    const uint32_t total_chunks = (uint32_t)(((uint64_t)n + TRACE_CHUNK - 1) / TRACE_CHUNK);
+    #ifdef TRACE_HOME_XCC
+    /* HW_REG_XCC_ID (hardware register 20, bits 3:0): the XCD this wave runs on */
+    const uint32_t home = ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % TRACE_REGIONS;
+#else
+    const uint32_t home = blockIdx.x % TRACE_REGIONS;
+#endif
+    uint32_t tried = 0;                   /* wave-uniform: regions found empty so far */
+    const bool scene_tame = root_is_tame(sc.root);
 
     while (true) {
         /* ---- refill idle lanes ---- */
@@ -179,12 +205,23 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
                 if (pool_next >= pool_end) {
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(a.d_next_chunk, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
-                    uint64_t first = (uint64_t)c * TRACE_CHUNK;
-                    if (first >= n) exhausted = true;
-                    else { pool_next = (uint32_t)first; pool_end = (uint32_t)min((uint64_t)n, first + TRACE_CHUNK); }
+                    exhausted = true;
+                    while (tried < (uint32_t)TRACE_REGIONS) {
+                        const uint32_t reg = (home + tried) % TRACE_REGIONS;
+                        const uint32_t lo = (uint32_t)(((uint64_t)reg * total_chunks) / TRACE_REGIONS);
+                        const uint32_t hi = (uint32_t)(((uint64_t)(reg + 1u) * total_chunks) / TRACE_REGIONS);
+                        uint32_t c = 0;
+                        if (lane == 0) c = atomicAdd(a.d_next_chunk + reg, 1u);
+                        c = __builtin_amdgcn_readfirstlane(c);
+                        if (c < hi - lo) {
+                            const uint64_t first = (uint64_t)(lo + c) * TRACE_CHUNK;
+                            pool_next = (uint32_t)first;
+                            pool_end = (uint32_t)min((uint64_t)n, first + TRACE_CHUNK);
+                            exhausted = false;
+                            break;
+                        }
+                        tried++;
+                    }
                 }
                 if (!exhausted) {
                     uint32_t k = pool_next + (uint32_t)__popcll(idle & lt_mask);
@@ -219,7 +256,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
 
         /* ---- one step per lane ---- */
         if (do_tri) lane_tri<ANY>(L, tr);
-        if (do_node) lane_node<ANY>(L, nd, st);
+        if (__any(do_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
+            if (do_node) lane_node<ANY, false>(L, nd, st);
+        } else {
+            if (do_node) lane_node<ANY, true>(L, nd, st);
+        }
 
         /* ---- retire finished rays ---- */
         if (active && lane_finished(L)) {
@@ -247,7 +288,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(DScene sc, TraceArgs a) {
             else {
                 L.r = nr;
                 ray_set_recip(L.r);
-                lane_start(L, sc.root_ref, sc.root);
+                lane_start(L, sc.root_ref, sc.root, scene_tame);
                 ray = (int32_t)new_ray;
                 dist = ndist;
             }
@@ -294,20 +335,18 @@ struct RenderBuffers {
     float *sh_dist, *sh_wr, *sh_wg, *sh_wb;
     uint8_t* sh_vis;
     uint32_t* sh_defer;
-    /* counters: [0..11] queue length per depth, [12..23] trace chunk counters (closest),
-     * [24..35] shadow-ray count per depth, [36..47] chunk counters (shadow any),
-     * [48..59] chunk counters (shadow exact), [60] camera samples,
-     * [64..75] shadow rays per depth that need the exact pass */
+    /* counters: [0..11] queue length per depth, [12..23] shadow-ray count per depth,
+     * [24..35] shadow rays per depth that need the exact pass, [36] camera samples,
+     * [64..] the queue-region heads of every trace launch of the batch */
     uint32_t* cnt;
 };
 #define CNT_QUEUE 0
-#define CNT_CHUNK_CLOSEST 12
-#define CNT_SHADOW 24
-#define CNT_CHUNK_ANY 36
-#define CNT_CHUNK_EXACT 48
-#define CNT_SAMPLES 60
-#define CNT_DEFER 64
-#define CNT_WORDS 80
+#define CNT_SHADOW 12
+#define CNT_DEFER 24
+#define CNT_SAMPLES 36
+#define CNT_CHUNKS 64            /* 8 queue-region heads per (kind, depth): 64 + (kind*12 + depth)*8 */
+#define CNT_CHUNK(kind, depth) (CNT_CHUNKS + ((kind) * 12 + (depth)) * 8)
+#define CNT_WORDS (CNT_CHUNKS + 3 * 12 * 8)
 
 __device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_sp, uint32_t p) {
     uint32_t lo = 0, hi = n_sp;
@@ -501,7 +540,7 @@ struct pt_scene {
     void* d_tris = nullptr;
     void* d_shade = nullptr;
     uint64_t n_tris = 0;
-    uint32_t* d_small = nullptr; /* [0] ray count, [1..2] chunk counters, [3] deferred count (raycast entry points) */
+    uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, [8..15] and [16..23] queue heads */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
     uint32_t* d_defer = nullptr; /* deferred shadow rays of pt_raycast_shadow_dev */
     uint64_t defer_cap = 0;
@@ -626,7 +665,7 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     size_t tb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_isect);
     size_t sb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_shade);
     if (hipMalloc(&s->d_nodes, nb) != hipSuccess || hipMalloc(&s->d_tris, tb) != hipSuccess ||
-        hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, 16 * sizeof(uint32_t)) != hipSuccess)
+        hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, 32 * sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(PT_ERR_DEVICE, "hipMalloc failed for the scene arrays"));
     bool ok = true;
     if (flat->n_nodes) ok = ok && hipMemcpy(s->d_nodes, flat->nodes, flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
@@ -735,11 +774,11 @@ int pt_raycast_closest_dev(pt_scene* s, uint64_t n, const float* ox, const float
     int rc = set_device(s);
     if (rc) return rc;
     if (s->n_tris == 0) return fill_miss_closest(s, n, idx, t, u, v);
-    uint32_t init[2] = {(uint32_t)n, 0u};
+    uint32_t init[32] = {(uint32_t)n};
     HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
     TraceArgs a{};
     a.rays = {ox, oy, oz, dx, dy, dz};
-    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 1;
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 8;
     a.out_idx = idx; a.out_t = t; a.out_u = u; a.out_v = v;
     return launch_trace<TRACE_CLOSEST_MESH>(s, a);
 }
@@ -760,16 +799,16 @@ int pt_raycast_shadow_dev(pt_scene* s, uint64_t n, const float* ox, const float*
         HIP_TRY(hipMalloc((void**)&s->d_defer, n * sizeof(uint32_t)));
         s->defer_cap = n;
     }
-    uint32_t init[4] = {(uint32_t)n, 0u, 0u, 0u};
+    uint32_t init[32] = {(uint32_t)n};
     HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
     TraceArgs a{};
     a.rays = {ox, oy, oz, dx, dy, dz};
-    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 1;
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 8;
     a.dist = dist; a.vis = vis;
-    a.defer_list = s->d_defer; a.defer_count = s->d_small + 3;
+    a.defer_list = s->d_defer; a.defer_count = s->d_small + 1;
     rc = launch_trace<TRACE_SHADOW_ANY>(s, a);
     if (rc) return rc;
-    a.d_count = s->d_small + 3; a.d_next_chunk = s->d_small + 2;
+    a.d_count = s->d_small + 1; a.d_next_chunk = s->d_small + 16;
     return launch_trace<TRACE_SHADOW_EXACT>(s, a);
 }
 
@@ -851,7 +890,7 @@ struct pt_film {
 
 static size_t batch_paths_limit() {
     const char* e = getenv("PT_BATCH_PATHS");
-    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 22;
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 26;
     if (v < 4096) v = 4096;
     if (v > ((size_t)1 << 27)) v = (size_t)1 << 27;
     return v;
@@ -943,7 +982,7 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
         TraceArgs a{};
         a.rays = {b.q[cur].ox, b.q[cur].oy, b.q[cur].oz, b.q[cur].dx, b.q[cur].dy, b.q[cur].dz};
         a.d_count = b.cnt + CNT_QUEUE + depth;
-        a.d_next_chunk = b.cnt + CNT_CHUNK_CLOSEST + depth;
+        a.d_next_chunk = b.cnt + CNT_CHUNK(0, depth);
         a.out_idx = b.hit_tri; a.out_t = b.hit_t; a.out_u = b.hit_u; a.out_v = b.hit_v;
         int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a);
         if (rc) return rc;
@@ -957,13 +996,13 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
             TraceArgs sa{};
             sa.rays = {b.sh.ox, b.sh.oy, b.sh.oz, b.sh.dx, b.sh.dy, b.sh.dz};
             sa.d_count = b.cnt + CNT_SHADOW + depth;
-            sa.d_next_chunk = b.cnt + CNT_CHUNK_ANY + depth;
+            sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
             sa.dist = b.sh_dist; sa.vis = b.sh_vis;
             sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
             rc = launch_trace<TRACE_SHADOW_ANY>(s, sa);
             if (rc) return rc;
             sa.d_count = b.cnt + CNT_DEFER + depth;
-            sa.d_next_chunk = b.cnt + CNT_CHUNK_EXACT + depth;
+            sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
             rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa);
             if (rc) return rc;
             ScopedTimer tm(s, PT_KERNEL_ACCUMULATE);
@@ -1072,8 +1111,10 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     bool lights_uploaded = false;
     auto flush = [&]() -> int {
         if (batch.empty()) return PT_OK;
-        size_t cap = 65536;
-        while (cap < batch_paths) cap <<= 1;
+        /* Large batches matter: a trace launch pays a fixed ramp-up and tail of a few hundred
+         * microseconds (the latency of its longest rays), so queues of tens of millions of rays
+         * are needed to run the kernels near their asymptotic rate. */
+        size_t cap = ((batch_paths + ((size_t)1 << 20) - 1) >> 20) << 20;
         int r2 = film_ensure_scratch(f, cap, (uint32_t)n_lights, batch.size());
         if (r2) return r2;
         if (!lights_uploaded && n_lights > 0) {

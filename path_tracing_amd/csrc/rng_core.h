@@ -12,9 +12,9 @@
  *   stream 16 + 16*depth + l  path vertex `depth` (0 = first hit), light l: words 0..2 are the
  *                             three light-delocalisation normals (:121)
  *   uniform  = ((word >> 8) + 0.5) / 2^24          in (0,1), exact in binary32 and binary64
- *   normal   = inverse normal CDF (Acklam's rational approximation) of the uniform,
- *              evaluated in binary64 with +,-,*,/ only, plus one binary32 square root, so
- *              that the CPU checker and the GPU produce the same bits; narrowed to binary32.
+ *   normal   = sqrt(2) * erfinv(+-(j + 0.5) / 2^23), sign and j from the word, erfinv by
+ *              Giles' binary32 polynomials and a logarithm built from +,-,*,/ only, plus one
+ *              binary32 square root, so that the CPU checker and the GPU produce the same bits.
  *
  * Compiled by hipcc for the kernels and by g++ for the CPU-side lane emulation used in tests.
  * Needs -ffp-contract=off.
@@ -64,65 +64,64 @@ PT_HD Rng4 rng_block(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t st
 
 PT_HD double uniform01(uint32_t w) { return ((double)(w >> 8) + 0.5) * (1.0 / 16777216.0); }
 
-PT_HD double u2d(uint64_t u) { union { double d; uint64_t u; } c; c.u = u; return c.d; }
-PT_HD uint64_t d2u(double d) { union { double d; uint64_t u; } c; c.d = d; return c.u; }
-
-/* ln(x) for normal x in (0, 1]: x = m * 2^e with m in (sqrt(1/2), sqrt(2)],
- * ln m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^23. */
-PT_HD double det_log(double x) {
-    uint64_t bits = d2u(x);
-    int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    double m = u2d((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double p = 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+/* ln(y) for a normal binary32 y in (0, 2): y = m * 2^e with m in (sqrt(1/2), sqrt(2)],
+ * ln m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^9.  Only +, -, *, / on binary32, so every
+ * IEEE machine agrees on the bits (absolute error below 1e-6). */
+PT_HD float det_logf(float y) {
+    uint32_t bits = f2u(y);
+    int e = (int)((bits >> 23) & 0xffu) - 127;
+    float m = u2f((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = 1.0f / 9.0f;
+    p = p * z + 1.0f / 7.0f;
+    p = p * z + 1.0f / 5.0f;
+    p = p * z + 1.0f / 3.0f;
+    p = p * z + 1.0f;
+    return (float)e * 0.693147182f + (2.0f * s) * p;
 }
 
-PT_HD double acklam_tail(double q) {
-    const double c0 = -7.784894002430293e-03, c1 = -3.223964580411365e-01, c2 = -2.400758277161838e+00,
-                 c3 = -2.549732539343734e+00, c4 = 4.374664141464968e+00, c5 = 2.938163982698783e+00;
-    const double d0 = 7.784695709041462e-03, d1 = 3.224671290700398e-01, d2 = 2.445134137142996e+00,
-                 d3 = 3.754408661907416e+00;
-    return (((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) / ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0);
-}
-
-PT_HD float normal_from_uniform(double p) {
-    const double a0 = -3.969683028665376e+01, a1 = 2.209460984245205e+02, a2 = -2.759285104469687e+02,
-                 a3 = 1.383577518672690e+02, a4 = -3.066479806614716e+01, a5 = 2.506628277459239e+00;
-    const double b0 = -5.447609879822406e+01, b1 = 1.615858368580409e+02, b2 = -1.556989798598866e+02,
-                 b3 = 6.680131188771972e+01, b4 = -1.328068155288572e+01;
-    const double p_low = 0.02425;
-    double x;
-    if (p < p_low) {
-        double q = (double)pt_sqrtf((float)(-2.0 * det_log(p)));
-        x = acklam_tail(q);
-    } else if (p <= 1.0 - p_low) {
-        double q = p - 0.5;
-        double r = q * q;
-        x = (((((a0 * r + a1) * r + a2) * r + a3) * r + a4) * r + a5) * q /
-            (((((b0 * r + b1) * r + b2) * r + b3) * r + b4) * r + 1.0);
+/* Inverse error function in binary32 (M. Giles, "Approximating the erfinv function",
+ * GPU Computing Gems, 2011): two polynomial branches, no division; absolute error < 5e-7. */
+PT_HD float det_erfinvf(float x) {
+    float w = -det_logf((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
     } else {
-        double q = (double)pt_sqrtf((float)(-2.0 * det_log(1.0 - p)));
-        x = -acklam_tail(q);
+        w = pt_sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
     }
-    return (float)x;
+    return p * x;
 }
 
-PT_HD float normal_from_word(uint32_t w) { return normal_from_uniform(uniform01(w)); }
+/* Standard normal from one random word by inverse CDF: bit 31 is the sign, bits 30..8 pick
+ * one of 2^23 cell midpoints x = (j + 0.5) / 2^23 in (0, 1) (exact in binary32, never 0 or 1),
+ * and the variate is sqrt(2) * erfinv(+-x). */
+PT_HD float normal_from_word(uint32_t w) {
+    float x = ((float)((w >> 8) & 0x7fffffu) + 0.5f) * (1.0f / 8388608.0f);
+    if (w & 0x80000000u) x = -x;
+    return 1.41421354f * det_erfinvf(x);
+}
 
 } // namespace ptc
 

@@ -76,6 +76,33 @@ PT_HD bool box_hit(float mnx, float mny, float mnz, float mxx, float mxy, float 
     return true;
 }
 
+/* Same test with hardware min/max (v_min_f32, v_max3_f32 ...).  IEEE minNum/maxNum differ from
+ * the select forms above only when an operand is NaN, or in the sign of a zero result.  A NaN
+ * needs 0*inf or inf-inf, which cannot occur when the ray's reciprocals are finite and
+ * non-zero and origin and box coordinates are finite and of moderate size (lane_is_tame);
+ * the sign of zero never changes the two comparisons below.  So for tame rays both forms give
+ * the same answer, and this one is about a third cheaper. */
+PT_HD bool box_hit_tame(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const Ray9& r) {
+    float t0x = (mnx - r.ox) * r.rx, t0y = (mny - r.oy) * r.ry, t0z = (mnz - r.oz) * r.rz;
+    float t1x = (mxx - r.ox) * r.rx, t1y = (mxy - r.oy) * r.ry, t1z = (mxz - r.oz) * r.rz;
+    float enx = __builtin_fminf(t0x, t1x), eny = __builtin_fminf(t0y, t1y), enz = __builtin_fminf(t0z, t1z);
+    float exx = __builtin_fmaxf(t0x, t1x), exy = __builtin_fmaxf(t0y, t1y), exz = __builtin_fmaxf(t0z, t1z);
+    float t_start = __builtin_fmaxf(enx, __builtin_fmaxf(eny, enz));
+    float t_end = __builtin_fminf(exx, __builtin_fminf(exy, exz));
+    return !(t_end < 0.0f) && !(t_start > t_end);
+}
+
+/* A ray is tame when no box test on it can produce a NaN: finite, non-zero reciprocals
+ * (no axis-parallel or infinite direction component) and a finite origin of moderate size.
+ * Box coordinates are bounded by the root box, which the scene checks once. */
+PT_HD bool ray_is_tame(const Ray9& r) {
+    const float big = 1.0e30f;
+    bool ok = __builtin_fabsf(r.rx) < big && __builtin_fabsf(r.ry) < big && __builtin_fabsf(r.rz) < big;
+    ok = ok && r.rx != 0.0f && r.ry != 0.0f && r.rz != 0.0f;
+    ok = ok && __builtin_fabsf(r.ox) < big && __builtin_fabsf(r.oy) < big && __builtin_fabsf(r.oz) < big;
+    return ok;
+}
+
 /* The reference compares det and t with the DOUBLE literal 1e-8.  (float)1e-8 is the largest
  * binary32 value below 1e-8, hence for a float x:  x < 1e-8  <=>  x <= EPS_F,
  * x > -1e-8 <=> x >= -EPS_F,  x <= 1e-8 <=> x <= EPS_F. */
@@ -130,11 +157,18 @@ struct StepOut {
     float t_far;
 };
 
+template <bool TAME>
 PT_HD StepOut interior_step(const NodeData& n, const Ray9& r) {
     StepOut o;
     o.next = PT_REF_NONE; o.deferred = PT_REF_NONE; o.far = PT_REF_NONE; o.t_far = 0.0f;
-    bool hit_lo = box_hit(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], r);
-    bool hit_hi = box_hit(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], r);
+    bool hit_lo, hit_hi;
+    if (TAME) {
+        hit_lo = box_hit_tame(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], r);
+        hit_hi = box_hit_tame(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], r);
+    } else {
+        hit_lo = box_hit(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], r);
+        hit_hi = box_hit(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], r);
+    }
     float origin = ray_origin_axis(r, n.axis);
     float hi_min_a = pick3(n.hi_min, n.axis), lo_max_a = pick3(n.lo_max, n.axis);
     bool over_hi = hi_min_a < origin;  /* :310 */
@@ -171,6 +205,13 @@ struct Hit {
 /* The root's own box (every other node's box is stored in its parent). */
 struct RootBox { float mnx, mny, mnz, mxx, mxy, mxz; };
 
+/* Every box of the tree lies inside the root box, so this bounds all box coordinates. */
+PT_HD bool root_is_tame(const RootBox& b) {
+    const float big = 1.0e30f;
+    return __builtin_fabsf(b.mnx) < big && __builtin_fabsf(b.mny) < big && __builtin_fabsf(b.mnz) < big &&
+           __builtin_fabsf(b.mxx) < big && __builtin_fabsf(b.mxy) < big && __builtin_fabsf(b.mxz) < big;
+}
+
 PT_HD uint32_t ref_is_leaf(uint32_t ref) { return ref & PT_REF_LEAF; }
 PT_HD uint32_t ref_leaf_start(uint32_t ref) { return ref & PT_REF_START_MASK; }
 PT_HD uint32_t ref_leaf_count(uint32_t ref) { return (ref >> PT_REF_COUNT_SHIFT) & PT_REF_COUNT_MASK; }
@@ -202,8 +243,8 @@ PT_HD uint32_t ref_leaf_count(uint32_t ref) { return (ref >> PT_REF_COUNT_SHIFT)
  *   interior node  (cur != NONE)           -> lane_node() with that node
  *   neither, stack not empty               -> lane_pop()
  *   neither, stack empty                   -> finished
- * Stack supplies push(int& sp, uint32_t) and pop(int& sp), which move the lane's stack pointer,
- * and is private to the lane.
+ * Stack supplies push(int& sp, uint32_t), which advances the lane's stack pointer, and
+ * peek(int index), which reads entry `index` (any value for index < 0); it is private to the lane.
  */
 struct Lane {
     Ray9 r;
@@ -215,6 +256,7 @@ struct Lane {
     uint32_t frame_bits;
     int sp;
     bool found;
+    bool tame;                   /* ray_is_tame(r) and the scene's boxes are of moderate size */
 };
 #define PT_LEAF_UNKNOWN 0xffffffffu
 
@@ -234,8 +276,9 @@ PT_HD void lane_enter(Lane& L, uint32_t ref) {
     }
 }
 
-PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root) {
+PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root, bool scene_tame) {
     const float inf = pt_inf();
+    L.tame = scene_tame && ray_is_tame(L.r);
     L.best.t = inf; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0xffffffffu; L.best.mesh = 0xffffffffu;
     L.local = inf;
     L.leaf_pos = 0; L.leaf_end = 0;
@@ -245,26 +288,34 @@ PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root) {
 
 template <bool ANYHIT, class Stack>
 PT_HD void lane_pop(Lane& L, Stack& st) {
-    uint32_t e = st.pop(L.sp);
-    if (!ANYHIT && (e & PT_REF_FRAME)) {
-        const float inf = pt_inf();
-        float t_far = u2f(st.pop(L.sp));
-        float saved = inf;
-        if (L.frame_bits & 1u) saved = u2f(st.pop(L.sp));
-        L.frame_bits >>= 1;
-        float near_local = L.local;
-        /* near side missed (:393-394) or its closest hit lies beyond the far slab (:367) */
-        bool visit = !(near_local < inf) || (near_local > t_far);
-        L.local = saved < near_local ? saved : near_local;
-        lane_enter(L, visit ? (e & ~PT_REF_FRAME) : PT_REF_NONE);
-    } else {
-        lane_enter(L, e);
+    /* The top three entries are read together (a frame is at most three dwords) so that the
+     * reads do not wait on one another; how many are consumed is decided afterwards. */
+    uint32_t e = st.peek(L.sp - 1);
+    if (!ANYHIT) {
+        uint32_t w1 = st.peek(L.sp - 2), w2 = st.peek(L.sp - 3);
+        if (e & PT_REF_FRAME) {
+            const float inf = pt_inf();
+            float t_far = u2f(w1);
+            bool kept = (L.frame_bits & 1u) != 0;
+            float saved = kept ? u2f(w2) : inf;
+            L.sp -= kept ? 3 : 2;
+            L.frame_bits >>= 1;
+            float near_local = L.local;
+            /* near side missed (:393-394) or its closest hit lies beyond the far slab (:367) */
+            bool visit = !(near_local < inf) || (near_local > t_far);
+            L.local = saved < near_local ? saved : near_local;
+            lane_enter(L, visit ? (e & ~PT_REF_FRAME) : PT_REF_NONE);
+            return;
+        }
     }
+    L.sp -= 1;
+    lane_enter(L, e);
 }
 
-template <bool ANYHIT, class Stack>
+/* TAME selects the cheaper box test; it may be used only for lanes with L.tame set. */
+template <bool ANYHIT, bool TAME, class Stack>
 PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
-    StepOut o = interior_step(n, L.r);
+    StepOut o = interior_step<TAME>(n, L.r);
     if (o.deferred != PT_REF_NONE) st.push(L.sp, o.deferred);
     if (o.far != PT_REF_NONE) {
         if (ANYHIT) st.push(L.sp, o.far);
@@ -300,10 +351,14 @@ template <bool ANYHIT, class Mem, class Stack>
 PT_HD bool trace_lane(const Mem& mem, uint32_t root_ref, const RootBox& root, const Ray9& r, Stack& st, Hit& best) {
     Lane L;
     L.r = r;
-    lane_start(L, root_ref, root);
+    lane_start(L, root_ref, root, root_is_tame(root));
     while (!lane_finished(L)) {
         if (lane_has_leaf(L)) { TriData tr; mem.load_tri(L.leaf_pos, tr); lane_tri<ANYHIT>(L, tr); }
-        else if (lane_has_node(L)) { NodeData n; mem.load_node(L.cur, n); lane_node<ANYHIT>(L, n, st); }
+        else if (lane_has_node(L)) {
+            NodeData n;
+            mem.load_node(L.cur, n);
+            if (L.tame) lane_node<ANYHIT, true>(L, n, st); else lane_node<ANYHIT, false>(L, n, st);
+        }
         else lane_pop<ANYHIT>(L, st);
     }
     best = L.best;

@@ -16,7 +16,8 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_PKG, "lib")
 HOST_LIB = os.path.join(LIB_DIR, "libpt_host.so")
-HIP_LIB = os.path.join(LIB_DIR, "libpt_hip.so")
+# PT_HIP_LIB selects another build of the same library (kernel tuning experiments).
+HIP_LIB = os.environ.get("PT_HIP_LIB") or os.path.join(LIB_DIR, "libpt_hip.so")
 
 PT_REF_LEAF = 0x80000000
 PT_REF_COUNT_SHIFT = 26

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sets", default="primary,sphere,shadow")
+    ap.add_argument("--sphere-rays", type=int, default=1 << 21)
     ap.add_argument("--check", action="store_true", help="compare a sample of results with the CPU oracle")
     args = ap.parse_args()
 
@@ -79,7 +80,7 @@ def main():
                 for g, w in zip(got, want)))
     if "sphere" in sets:
         rng = np.random.default_rng(1234)
-        m = 1 << 21
+        m = args.sphere_rays
         o = rng.normal(size=(m, 3))
         o = 3 * o / np.linalg.norm(o, axis=1, keepdims=True)
         tt = rng.normal(size=(m, 3))

@@ -40,7 +40,7 @@ struct CpuStack {
         data[sp++] = v;
         if (sp > max_sp) max_sp = sp;
     }
-    uint32_t pop(int& sp) { return data[--sp]; }
+    uint32_t peek(int i) const { return i >= 0 ? data[i] : 0u; }
 };
 
 ptc::RootBox root_of(const pt_flat_scene* sc) {

@@ -25,16 +25,25 @@ def test_philox_known_answers():
 def test_uniform_and_normal_transform():
     from scipy.stats import norm
     L = orc.lib()
-    words = np.concatenate([np.arange(0, 2 ** 32, 2 ** 32 // 4096, dtype=np.uint64),
-                            np.array([0, 255, 256, 2 ** 32 - 1, 2 ** 31, 2 ** 31 - 1], dtype=np.uint64)])
+    words = np.concatenate([np.arange(0, 2 ** 32, 2 ** 32 // 8192, dtype=np.uint64),
+                            np.array([0, 255, 256, 2 ** 32 - 1, 2 ** 31, 2 ** 31 - 1, 2 ** 31 - 256, 2 ** 32 - 256], dtype=np.uint64)])
     u = np.array([L.orc_uniform01(int(w)) for w in words])
     assert (u > 0).all() and (u < 1).all()
     assert u.min() == 0.5 / 2 ** 24 and u.max() == 1 - 0.5 / 2 ** 24
+    # normal: sign = bit 31, magnitude cell = bits 30..8; compare with the exact inverse CDF
     z = np.array([L.orc_normal_from_word(int(w)) for w in words], dtype=np.float64)
-    ref = norm.ppf(u)
-    assert np.abs(z - ref).max() < 5e-6 * np.maximum(1.0, np.abs(ref)).max()
-    # antisymmetric about the middle of the word range
-    assert L.orc_normal_from_word(0) == -L.orc_normal_from_word(2 ** 32 - 1)
+    j = ((words >> np.uint64(8)) & np.uint64(0x7FFFFF)).astype(np.float64)
+    x = (j + 0.5) / 2 ** 23
+    sign = np.where(words >= 2 ** 31, -1.0, 1.0)
+    ref = sign * norm.ppf(0.5 + 0.5 * x)
+    assert np.abs(z - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    assert np.isfinite(z).all() and np.abs(z).max() < 5.5
+    # antisymmetric in the sign bit
+    assert L.orc_normal_from_word(0x12345600) == -L.orc_normal_from_word(0x92345600)
+    # moments of a large sample
+    rng = np.random.default_rng(0)
+    zs = np.array([L.orc_normal_from_word(int(w)) for w in rng.integers(0, 2 ** 32, 200000, dtype=np.uint64)])
+    assert abs(zs.mean()) < 0.01 and abs(zs.std() - 1.0) < 0.01
 
 
 @pytest.mark.parametrize("which", ["scene_tiny", "scene_small", "scene_medium"])
