@@ -75,7 +75,7 @@ struct RaySoAW {
 #define STACK_LDS 16       /* dwords per lane kept in LDS; deeper entries spill to HBM (rare: <1 % of rays) */
 #endif
 #ifndef TRACE_CHUNK
-#define TRACE_CHUNK 64     /* rays a wave takes from the queue per atomic */
+#define TRACE_CHUNK 64     /* fewest rays a wave takes from the queue per atomic */
 #endif
 #ifndef REFILL_MIN
 #define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
@@ -140,7 +140,8 @@ enum TraceMode {
 
 struct TraceArgs {
     RaySoA rays;
-    const uint32_t* d_count; /* number of work items, in device memory */
+    const uint32_t* d_count; /* number of work items = *d_count * count_mul, in device memory */
+    uint32_t count_mul;
     uint32_t* d_next_chunk;  /* 8 atomic chunk counters (one per queue region), zero at launch */
     int32_t* out_idx;
     float *out_t, *out_u, *out_v;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY);
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
     __shared__ uint32_t stk[STACK_LDS * TRACE_BLOCK];
-    const uint32_t n = *a.d_count;
+    const uint32_t n = *a.d_count * a.count_mul;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     GpuMem mem;
@@ -186,7 +187,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     float dist = 0.0f;
     uint32_t pool_next = 0, pool_end = 0; /* wave-uniform: unclaimed rays of the current chunk */
     bool exhausted = false;               /* wave-uniform: the queue has no more chunks */
-    const uint32_t total_chunks = (uint32_t)(((uint64_t)n + TRACE_CHUNK - 1) / TRACE_CHUNK);
+    /* Chunk size: TRACE_CHUNK rays for short queues (finer balance in the tail), growing to 16x
+     * that for long ones so that the queue head sees far fewer atomics than it can sustain. */
+    uint32_t chunk = TRACE_CHUNK;
+    {
+        const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
+        while (chunk < 16u * TRACE_CHUNK && (uint64_t)chunk * 2u * 16u * waves <= n) chunk *= 2u;
+    }
+    const uint32_t total_chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
     #ifdef TRACE_HOME_XCC
     /* HW_REG_XCC_ID (hardware register 20, bits 3:0): the XCD this wave runs on */
     const uint32_t home = ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % TRACE_REGIONS;
@@ -214,9 +222,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
                         if (lane == 0) c = atomicAdd(a.d_next_chunk + reg, 1u);
                         c = __builtin_amdgcn_readfirstlane(c);
                         if (c < hi - lo) {
-                            const uint64_t first = (uint64_t)(lo + c) * TRACE_CHUNK;
+                            const uint64_t first = (uint64_t)(lo + c) * chunk;
                             pool_next = (uint32_t)first;
-                            pool_end = (uint32_t)min((uint64_t)n, first + TRACE_CHUNK);
+                            pool_end = (uint32_t)min((uint64_t)n, first + chunk);
                             exhausted = false;
                             break;
                         }
@@ -357,8 +365,31 @@ __device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_s
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_generate(CamParams cam, const SubPass* sp, uint32_t n_sp, uint32_t n_paths,
-                                                   uint64_t seed, RenderBuffers b) {
+#define STREAM_BLOCK 512
+
+/* Workgroup-wide stream compaction: every thread calls it; threads with `flag` get distinct
+ * consecutive slots starting at a base taken from *counter with ONE atomic per workgroup (a
+ * single counter sustains only ~90 M atomics per second, which one atomic per wave would
+ * exceed at these queue sizes).  s_wave needs STREAM_BLOCK/64 + 1 words of LDS. */
+__device__ __forceinline__ uint32_t block_compact(bool flag, uint32_t* counter, uint32_t* s_wave) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    constexpr uint32_t NW = STREAM_BLOCK / 64;
+    const uint64_t mask = __ballot(flag);
+    __syncthreads(); /* previous use of s_wave is over */
+    if (lane == 0) s_wave[wid] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < NW; w++) { uint32_t t = s_wave[w]; s_wave[w] = total; total += t; }
+        s_wave[NW] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    return s_wave[NW] + s_wave[wid] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(STREAM_BLOCK) void k_generate(CamParams cam, const SubPass* sp, uint32_t n_sp, uint32_t n_paths,
+                                                            uint64_t seed, RenderBuffers b) {
+    __shared__ uint32_t s_wave[STREAM_BLOCK / 64 + 1];
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     int px = 0, py = 0;
@@ -379,18 +410,9 @@ __global__ __launch_bounds__(256) void k_generate(CamParams cam, const SubPass* 
         b.pixel[p] = pixel; b.sample[p] = sample;
         b.rad_r[p] = 0.0f; b.rad_g[p] = 0.0f; b.rad_b[p] = 0.0f; b.thr[p] = 1.0f;
     }
-    /* compact valid paths into queue 0: one atomic per wave */
-    uint64_t mask = __ballot(valid);
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == 0 && mask) {
-        uint32_t c = (uint32_t)__popcll(mask);
-        base = atomicAdd(&b.cnt[CNT_QUEUE + 0], c);
-        atomicAdd(&b.cnt[CNT_SAMPLES], c);
-    }
-    base = __builtin_amdgcn_readfirstlane(base);
+    /* compact valid paths (rectangles that are not multiples of 8 pixels have padding) into queue 0 */
+    uint32_t slot = block_compact(valid, &b.cnt[CNT_QUEUE + 0], s_wave);
     if (valid) {
-        uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         V3f o, d;
         camera_ray_jittered(cam, px, py, sample, seed, o, d);
         b.q[0].ox[slot] = o.x; b.q[0].oy[slot] = o.y; b.q[0].oz[slot] = o.z;
@@ -413,13 +435,13 @@ __global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int 
 }
 
 /* Hit branch of cast_ray for every ray of the current queue (cur = depth & 1). */
-__global__ __launch_bounds__(256) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
-                                                uint32_t depth, int last_depth, uint64_t seed, RenderBuffers b) {
+__global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
+                                                         uint32_t depth, int last_depth, uint64_t seed, RenderBuffers b) {
+    __shared__ uint32_t s_wave[STREAM_BLOCK / 64 + 1];
     const uint32_t n = b.cnt[CNT_QUEUE + depth];
     const int cur = depth & 1, nxt = cur ^ 1;
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base_i = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); base_i < n; base_i += gridDim.x * blockDim.x) {
-        uint32_t i = base_i + lane;
+    for (uint32_t base_i = blockIdx.x * STREAM_BLOCK; base_i < n; base_i += gridDim.x * STREAM_BLOCK) {
+        uint32_t i = base_i + threadIdx.x;
         bool hit = false;
         uint32_t path = 0;
         int32_t tri = -1;
@@ -434,16 +456,9 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, CamParams cam, const D
                 }
             }
         }
-        uint64_t mask = __ballot(hit);
-        uint32_t wbase = 0;
-        if (lane == 0 && mask) {
-            uint32_t c = (uint32_t)__popcll(mask);
-            wbase = atomicAdd(&b.cnt[CNT_QUEUE + depth + 1], c);
-            atomicAdd(&b.cnt[CNT_SHADOW + depth], c * n_lights);
-        }
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        /* surviving paths keep one slot in the next queue and n_lights slots in the shadow queue */
+        const uint32_t slot = block_compact(hit, &b.cnt[CNT_QUEUE + depth + 1], s_wave);
         if (hit) {
-            uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             const float4* sp = sc.shade + (size_t)tri * 4;
             float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
             ShadeTri st;
@@ -732,6 +747,7 @@ template <int MODE>
 static int launch_trace(pt_scene* s, TraceArgs a) {
     if (s->pending.size() > 8192) { int rc = resolve_timing(s); if (rc) return rc; }
     a.spill = s->d_spill;
+    if (a.count_mul == 0) a.count_mul = 1;
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW);
     hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY)), dim3(TRACE_BLOCK), 0, s->stream, s->d, a);
     HIP_TRY(hipGetLastError());
@@ -972,11 +988,12 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
     HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, s->stream));
     {
         ScopedTimer tm(s, PT_KERNEL_GENERATE);
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + 255) / 256), dim3(256), 0, s->stream, cam, f->d_sub, (uint32_t)sub.size(),
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + STREAM_BLOCK - 1) / STREAM_BLOCK), dim3(STREAM_BLOCK), 0, s->stream, cam, f->d_sub, (uint32_t)sub.size(),
                            n_paths, seed, b);
         HIP_TRY(hipGetLastError());
     }
     const int light_grid = s->num_cus * 8;
+    const int shade_grid = s->num_cus * 4;
     for (uint32_t depth = 0; depth <= 10; depth++) { /* cast_ray(ray, 10, 1): recursions 10..0 */
         const int cur = depth & 1;
         TraceArgs a{};
@@ -988,20 +1005,22 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
         if (rc) return rc;
         {
             ScopedTimer tm(s, PT_KERNEL_SHADE);
-            hipLaunchKernelGGL(k_shade, dim3(light_grid), dim3(256), 0, s->stream, s->d, cam, f->d_lights, n_lights, depth,
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, s->stream, s->d, cam, f->d_lights, n_lights, depth,
                                depth == 10 ? 1 : 0, seed, b);
             HIP_TRY(hipGetLastError());
         }
         if (n_lights > 0) {
             TraceArgs sa{};
             sa.rays = {b.sh.ox, b.sh.oy, b.sh.oz, b.sh.dx, b.sh.dy, b.sh.dz};
-            sa.d_count = b.cnt + CNT_SHADOW + depth;
+            sa.d_count = b.cnt + CNT_QUEUE + depth + 1; /* one shadow ray per surviving path and light */
+            sa.count_mul = n_lights;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
             sa.dist = b.sh_dist; sa.vis = b.sh_vis;
             sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
             rc = launch_trace<TRACE_SHADOW_ANY>(s, sa);
             if (rc) return rc;
             sa.d_count = b.cnt + CNT_DEFER + depth;
+            sa.count_mul = 1;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
             rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa);
             if (rc) return rc;
@@ -1020,8 +1039,8 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
         uint32_t h[CNT_WORDS];
         HIP_TRY(hipMemcpyAsync(h, b.cnt, sizeof(h), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        counts[0] += h[CNT_SAMPLES];
-        for (int d = 0; d <= 10; d++) { counts[1] += h[CNT_QUEUE + d]; counts[2] += h[CNT_SHADOW + d]; }
+        counts[0] += h[CNT_QUEUE + 0];
+        for (int d = 0; d <= 10; d++) { counts[1] += h[CNT_QUEUE + d]; counts[2] += (uint64_t)h[CNT_QUEUE + d + 1] * n_lights; }
     }
     return PT_OK;
 }
