@@ -19,7 +19,7 @@ HIPFLAGS := -std=c++17 -O3 $(STRICT) -fhip-fp32-correctly-rounded-divide-sqrt -f
 HIP_SRCS := $(PKG)/csrc/pt_hip.hip
 HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) include/pt_hip.h
 
-all: host hip oracle native-tests
+all: host hip render oracle native-tests
 
 host: $(LIBDIR)/libpt_host.so
 hip: $(LIBDIR)/libpt_hip.so
@@ -34,6 +34,14 @@ $(LIBDIR)/libpt_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
 
+# The reference's C++ scene/render API on top of the C ABI, and its command-line front end.
+render: $(LIBDIR)/libpt_render.so $(PKG)/bin/cli_render
+$(LIBDIR)/libpt_render.so: $(PKG)/host/render_api.cpp include/pt_render.h include/pt_hip.h include/pt_host.h $(LIBDIR)/libpt_host.so $(LIBDIR)/libpt_hip.so
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(PKG)/host/render_api.cpp -L$(LIBDIR) -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN'
+$(PKG)/bin/cli_render: $(PKG)/host/cli_render.cpp include/pt_render.h $(LIBDIR)/libpt_render.so
+	mkdir -p $(PKG)/bin
+	$(CXX) $(HOSTFLAGS) -o $@ $(PKG)/host/cli_render.cpp -L$(LIBDIR) -lpt_render -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,$(ROCM)/lib
+
 # Lane-level emulation of the device traversal on the CPU (tests only).
 native-tests: tests/native/_build/libtraverse_emul.so
 tests/native/_build/libtraverse_emul.so: tests/native/traverse_emul.cpp $(PKG)/csrc/traverse_core.h include/pt_hip.h
@@ -41,7 +49,7 @@ tests/native/_build/libtraverse_emul.so: tests/native/traverse_emul.cpp $(PKG)/c
 	$(CXX) $(HOSTFLAGS) -I$(PKG)/csrc -shared -o $@ tests/native/traverse_emul.cpp
 
 clean:
-	rm -rf $(LIBDIR) tests/native/_build
+	rm -rf $(LIBDIR) $(PKG)/bin tests/native/_build
 	$(MAKE) -C oracle clean
 
-.PHONY: all host hip oracle native-tests clean
+.PHONY: all host hip render oracle native-tests clean

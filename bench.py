@@ -56,6 +56,19 @@ def host_threads(world):
     return max(1, min(16, avail // max(world, 1)) or 1)
 
 
+def measured_traffic(rays_per_launch):
+    """HBM-side bytes per launch of the closest-hit kernel, from the rocprofv3 PMC pass recorded in
+    profiles/traffic.json (FETCH_SIZE + WRITE_SIZE per ray of the same bench command, FETCH_SIZE
+    doubled as the gfx950 correction requires), scaled to this run's rays per launch."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fp:
+            t = json.load(fp)
+        return round(float(t["closest_bytes_per_ray"]) * rays_per_launch, 1)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +78,7 @@ def main():
     import torch.distributed as dist
 
     import path_tracing_amd as pta
-    from path_tracing_amd import native
+    from path_tracing_amd.distributed import reduce_film
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -108,8 +121,7 @@ def main():
         shadow += st.shadow_rays
         samples += st.camera_samples
     gpu.sync()
-    if world > 1:
-        dist.reduce(film_t, dst=0, op=dist.ReduceOp.SUM)  # Canvas::add_from over all workers
+    reduce_film(film_t, dst=0)  # Canvas::add_from over all workers: one RCCL reduce when world > 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -167,7 +179,7 @@ def main():
             oscene = orc.Scene(tris, threads=threads)
             t_oracle_build = time.time() - tb
             ocam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
-            # bounded sample: every 4th row-band of the same frame, 1 spp (a quarter of a pass)
+            # work per ray in the reference's visit order: every 4th 8-row band of the frame, 1 spp
             bands = [(0, y, W, min(8, H - y)) for y in range(0, H, 32)]
             work = np.zeros(6, dtype=np.uint64)
             rgb = np.zeros((H, W, 3), np.float32)
@@ -181,22 +193,26 @@ def main():
             b_closest = n_box_c * 32 + n_tri_c * 36 + 24 + 16
             b_shadow = n_box_s * 32 + n_tri_s * 36 + 24 + 1
             if world == 1:
-                tb = time.time()
+                # CPU baseline: whole passes of the same frame until about 20 s of CPU time are spent
                 rgb[:] = 0
                 pas[:] = 0
                 cnt = np.zeros(2, dtype=np.uint64)
-                for b in bands:
-                    _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, b, 0, 1, seed=args.seed, threads=threads,
-                                            rgb=rgb, passes=pas)
+                n_pass = 0
+                tb = time.time()
+                while True:
+                    _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, None, n_pass, 1, seed=args.seed,
+                                            threads=threads, rgb=rgb, passes=pas)
                     cnt += c
-                t_cpu = time.time() - tb
+                    n_pass += 1
+                    t_cpu = time.time() - tb
+                    if t_cpu * threads >= 20.0 or n_pass >= 64:
+                        break
                 n_samp = int(pas.sum())
                 cpu = {"value": round(float(cnt.sum()) / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": threads,
                        "kind": "port",
-                       "sample": "CPU oracle (strict-IEEE restatement of the reference path), %d threads, every 4th "
-                                 "8-row band of the same %dx%d frame at 1 spp = %d camera samples in %.2f s; "
-                                 "extrapolates to %.0f s per 1000 spp" % (threads, W, H, n_samp, t_cpu,
-                                                                          t_cpu / n_samp * W * H * 1000),
+                       "sample": "CPU oracle (strict-IEEE restatement of the reference path), %d threads, %d full "
+                                 "%dx%d passes = %d camera samples in %.2f s; extrapolates to %.0f s per 1000 spp"
+                                 % (threads, n_pass, W, H, n_samp, t_cpu, t_cpu / n_samp * W * H * 1000),
                        "camera_samples_per_s": round(n_samp / t_cpu, 1),
                        "oracle_scene_build_s": round(t_oracle_build, 2)}
             ms_c, launches_c = kt[0]
@@ -204,7 +220,7 @@ def main():
                 bytes_per_launch = closest / launches_c * b_closest   # rank 0's own launches
                 achieved = bytes_per_launch / (ms_c / launches_c * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(closest / launches_c),
                         "kernel": "k_trace<closest>",
                         "algorithmic_bytes_per_ray": round(float(b_closest), 1),
                         "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),

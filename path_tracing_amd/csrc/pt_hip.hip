@@ -80,6 +80,9 @@ struct RaySoAW {
 #ifndef REFILL_MIN
 #define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
 #endif
+#ifndef TRACE_TRIS_PER_ROUND
+#define TRACE_TRIS_PER_ROUND 1 /* triangles of a pending leaf tested per round (1 or 2) */
+#endif
 #ifndef TRACE_REGIONS
 #define TRACE_REGIONS 1    /* queue regions (one head each), at most 8.  Measured: 8 regions keyed by
                               XCD (blockIdx % 8 or HW_REG_XCC_ID) were 18-40 % SLOWER than one shared head */
@@ -254,6 +257,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         const bool do_tri = active && lane_has_leaf(L);
         TriData tr;
         if (do_tri) mem.load_tri(L.leaf_pos, tr);
+#if TRACE_TRIS_PER_ROUND >= 2
+        /* second triangle of the same leaf in the same round, when the leaf is known to have one */
+        const bool do_tri2 = do_tri && L.leaf_end != PT_LEAF_UNKNOWN && L.leaf_pos + 1u < L.leaf_end;
+        TriData tr2;
+        if (do_tri2) mem.load_tri(L.leaf_pos + 1u, tr2);
+#endif
         if (active && !do_tri && !lane_has_node(L) && L.sp > 0) {
             lane_pop<ANY>(L, st);
             if (!lane_has_node(L) && !lane_has_leaf(L) && L.sp > 0) lane_pop<ANY>(L, st);
@@ -264,6 +273,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
 
         /* ---- one step per lane ---- */
         if (do_tri) lane_tri<ANY>(L, tr);
+#if TRACE_TRIS_PER_ROUND >= 2
+        if (do_tri2 && lane_has_leaf(L)) lane_tri<ANY>(L, tr2);
+#endif
         if (__any(do_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
             if (do_node) lane_node<ANY, false>(L, nd, st);
         } else {

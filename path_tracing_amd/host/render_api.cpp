@@ -1,0 +1,567 @@
+/*
+ * render_api.cpp -- the reference's Scene / RenderEngine / Integrator / Canvas API on top of
+ * the C ABI of pt_hip.h (see include/pt_render.h for the contract and the differences).
+ *
+ * One RenderThread per GPU pulls tile passes from the engine's shared queue, exactly as the
+ * reference's CPU workers do (integrator.cpp:315-359), but takes as many queued passes as it
+ * can find in one go and hands them to pt_render_passes() as one batch: the GPU needs
+ * millions of rays in flight, a single 64x64 tile pass has 4096.
+ */
+#include "pt_render.h"
+
+#include <sys/time.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+using namespace std;
+
+long long rays_cast = 0;
+
+/* ------------------------------------------------------------------- utils */
+
+Ray::Ray() : origin(0, 0, 0), direction(0, 0, 1) {}
+Ray::Ray(Vec _origin, Vec _direction) : origin(_origin), direction(_direction) { direction.normalize(); }
+Real Ray::distance_along_ray(Vec p) const { return direction.dot(p - origin); }
+
+static bool thread_count_is_overridden = false;
+static int overridden_thread_count = 0;
+
+void override_thread_count(int thread_count) { /* utils.cpp:190-194: zero means automatic */
+    thread_count_is_overridden = thread_count != 0;
+    overridden_thread_count = thread_count;
+}
+
+/* Workers are GPUs here: the number of visible devices, or the override if smaller. */
+int get_optimal_thread_count() {
+    int n = 0;
+    if (pt_device_count(&n) != PT_OK || n <= 0) return 0;
+    if (thread_count_is_overridden && overridden_thread_count > 0) return min(n, overridden_thread_count);
+    return n;
+}
+
+string format_seconds_as_hms(double seconds, int width) { /* utils.cpp:231-264 */
+    string s;
+    bool is_negative = seconds < 0;
+    if (is_negative) seconds *= -1;
+    int total_seconds = (int)ceil(seconds);
+    int second_count = total_seconds % 60, minute_count = (total_seconds / 60) % 60, hour_count = total_seconds / 3600;
+    s = to_string(second_count);
+    if (s.size() == 1) s = "0" + s;
+    s = to_string(minute_count) + ":" + s;
+    if (total_seconds >= 3600) {
+        if (s.size() == 4) s = "0" + s;
+        s = to_string(hour_count) + ":" + s;
+    }
+    if (is_negative) s = "-" + s;
+    while ((int)s.size() < width) s = " " + s;
+    return s;
+}
+
+/* ------------------------------------------------------------ mesh and tree */
+
+static Vec vec3(const float* p) { return Vec(p[0], p[1], p[2]); }
+
+/* Triangle fields as the reference's constructor and set_normals leave them. */
+static void fill_triangles(const pth_scene* built, vector<Triangle>& tris) {
+    int64_t n = pth_num_triangles(built);
+    vector<float> data((size_t)n * 30);
+    pth_triangle_data(built, data.data());
+    tris.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        const float* d = &data[(size_t)i * 30];
+        Triangle& t = tris[(size_t)i];
+        for (int k = 0; k < 3; k++) t.points[k] = vec3(d + 3 * k);
+        t.edge01 = vec3(d + 9); t.edge02 = vec3(d + 12); t.normal = vec3(d + 15);
+        t.base_normal = vec3(d + 18); t.u_normal = vec3(d + 21); t.v_normal = vec3(d + 24);
+        for (int a = 0; a < 3; a++) {
+            t.aabb.minima(a) = real_min(real_min(t.points[0](a), t.points[1](a)), t.points[2](a));
+            t.aabb.maxima(a) = real_max(real_max(t.points[0](a), t.points[1](a)), t.points[2](a));
+        }
+        t.assigned_normal = t.normal;
+    }
+}
+
+void kdTreeNode::get_stats(int& deepest_depth, int& biggest_set) const {
+    if (deepest > deepest_depth) deepest_depth = deepest;
+    if (biggest > biggest_set) biggest_set = biggest;
+}
+
+static void finish_tree(kdTree* t, pth_scene* built, kdTreeNode*& root) {
+    int64_t st[5];
+    pth_tree_stats(built, st);
+    root = new kdTreeNode();
+    root->deepest = (int)st[2];
+    root->biggest = (int)st[3];
+    (void)t;
+}
+
+kdTree::kdTree(vector<Triangle>* _all_triangles) : all_triangles(_all_triangles), built(nullptr), root(nullptr) {
+    pthread_mutex_init(&lock, NULL);
+    vector<float> soup(all_triangles->size() * 9);
+    for (size_t i = 0; i < all_triangles->size(); i++)
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) soup[i * 9 + k * 3 + a] = (*all_triangles)[i].points[k](a);
+    built = pth_scene_from_triangles(soup.data(), (int64_t)all_triangles->size(), 0);
+    if (built) { fill_triangles(built, *all_triangles); finish_tree(this, built, root); }
+}
+
+kdTree::kdTree(vector<Triangle>* _all_triangles, pth_scene* prebuilt) : all_triangles(_all_triangles), built(prebuilt), root(nullptr) {
+    pthread_mutex_init(&lock, NULL);
+    if (built) finish_tree(this, built, root);
+}
+
+kdTree::~kdTree() {
+    for (pt_scene* s : on_device) pt_scene_destroy(s);
+    if (built) pth_scene_destroy(built);
+    delete root;
+    pthread_mutex_destroy(&lock);
+}
+
+pt_scene* kdTree::device_scene(int device) {
+    if (!built || device < 0) return nullptr;
+    pthread_mutex_lock(&lock);
+    if ((int)on_device.size() <= device) on_device.resize((size_t)device + 1, nullptr);
+    pt_scene* s = on_device[(size_t)device];
+    if (!s) {
+        if (pt_scene_create(device, pth_flat_scene(built), &s) != PT_OK) s = nullptr;
+        on_device[(size_t)device] = s;
+    }
+    pthread_mutex_unlock(&lock);
+    return s;
+}
+
+bool kdTree::ray_test(const Ray& ray, Real& hit_parameter, Real& hit_u, Real& hit_v, const Triangle** hit_triangle) {
+    pt_scene* s = device_scene(0);
+    if (!s) return false;
+    int32_t idx = -1;
+    float t = 0, u = 0, v = 0;
+    float o[3] = {ray.origin(0), ray.origin(1), ray.origin(2)}, d[3] = {ray.direction(0), ray.direction(1), ray.direction(2)};
+    pthread_mutex_lock(&lock);
+    int rc = pt_raycast_closest(s, 1, &o[0], &o[1], &o[2], &d[0], &d[1], &d[2], &idx, &t, &u, &v);
+    pthread_mutex_unlock(&lock);
+    __sync_fetch_and_add(&rays_cast, 1);
+    if (rc != PT_OK || idx < 0) return false;
+    hit_parameter = t; hit_u = u; hit_v = v;
+    if (hit_triangle != nullptr) *hit_triangle = &(*all_triangles)[(size_t)idx];
+    return true;
+}
+
+/* ------------------------------------------------------------------- scene */
+
+Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integrator.cpp:11-39 */
+    scene_up = Vec(0, 0, 1);
+    camera_image_plane_width = 1.0;
+    plane_of_focus_distance = 1.0;
+    dof_dispersion = 0.0;
+    sky_color = Vec(0, 0, 0);
+    mesh = nullptr; lights = nullptr; tree = nullptr;
+    pth_scene* built = pth_scene_from_stl(path.c_str(), 0);
+    if (built == nullptr) {
+        cout << "Couldn't read input file." << endl;
+        return;
+    }
+    mesh = new vector<Triangle>();
+    fill_triangles(built, *mesh);
+    cout << "Read in " << mesh->size() << " triangles." << endl;
+    /* adopt the already built tree instead of building it a second time from the points */
+    tree = new kdTree(mesh, built);
+    lights = new vector<Light>();
+}
+
+Scene::~Scene() {
+    delete tree;
+    delete mesh;
+    delete lights;
+}
+
+/* ------------------------------------------------------------------ canvas */
+
+PassDescriptor::PassDescriptor() : start_x(0), start_y(0), width(-1), height(-1) {}
+PassDescriptor::PassDescriptor(int sx, int sy, int w, int h) : start_x(sx), start_y(sy), width(w), height(h) {}
+void PassDescriptor::clamp_bounds(int max_width, int max_height) { /* integrator.cpp:164-183 */
+    if (start_x < 0) start_x = 0;
+    if (start_y < 0) start_y = 0;
+    if (start_x > max_width - 1) start_x = max_width - 1;
+    if (start_y > max_height - 1) start_y = max_height - 1;
+    if (width == -1) width = max_width;
+    if (height == -1) height = max_height;
+    if (width > max_width - start_x) width = max_width - start_x;
+    if (height > max_height - start_y) height = max_height - start_y;
+}
+
+Canvas::Canvas(int _width, int _height) : width(_width), height(_height), gain(255.0) {
+    size = width * height;
+    pixels = new Color[size];
+    per_pixel_passes = new int[size];
+    depth_buffer = new Real[size];
+}
+Canvas::~Canvas() { delete[] pixels; delete[] per_pixel_passes; delete[] depth_buffer; }
+void Canvas::zero() {
+    for (int i = 0; i < size; i++) { pixels[i] = Vec(0, 0, 0); per_pixel_passes[i] = 0; depth_buffer[i] = 0.0; }
+}
+Color* Canvas::pixel_ptr(int x, int y) { return pixels + (x + y * width); }
+int* Canvas::per_pixel_passes_ptr(int x, int y) { return per_pixel_passes + (x + y * width); }
+Real* Canvas::depth_ptr(int x, int y) { return depth_buffer + (x + y * width); }
+void Canvas::get_pixel(int x, int y, uint8_t* dest) { /* canvas.cpp:39-45 */
+    Color c = pixels[x + y * width] / real_max(per_pixel_passes[x + y * width], 1.0);
+    for (int i = 0; i < 3; i++) dest[i] = (uint8_t)real_max(0.0, real_min(255.0, (Real)(c(i) * gain)));
+}
+void Canvas::add_from(Canvas* other) { /* canvas.cpp:47-52 */
+    for (int i = 0; i < size; i++) { pixels[i] += other->pixels[i]; per_pixel_passes[i] += other->per_pixel_passes[i]; }
+}
+
+static void png_chunk(FILE* fp, const char* type, const unsigned char* data, size_t len) {
+    unsigned char hdr[8] = {(unsigned char)(len >> 24), (unsigned char)(len >> 16), (unsigned char)(len >> 8), (unsigned char)len,
+                            (unsigned char)type[0], (unsigned char)type[1], (unsigned char)type[2], (unsigned char)type[3]};
+    fwrite(hdr, 1, 8, fp);
+    if (len) fwrite(data, 1, len, fp);
+    uLong crc = crc32(0L, hdr + 4, 4);
+    if (len) crc = crc32(crc, data, (uInt)len);
+    unsigned char c[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8), (unsigned char)crc};
+    fwrite(c, 1, 4, fp);
+}
+
+/* 8-bit RGB, no interlace, like the reference's libpng call (canvas.cpp:55-131); written with
+ * zlib alone.  Returns 0 on success and -1 on any failure, never throws. */
+int Canvas::save(string path) {
+    FILE* fp = fopen(path.c_str(), "wb");
+    if (!fp) return -1;
+    vector<unsigned char> raw((size_t)height * ((size_t)width * 3 + 1));
+    for (int y = 0; y < height; y++) {
+        unsigned char* row = &raw[(size_t)y * ((size_t)width * 3 + 1)];
+        row[0] = 0;
+        for (int x = 0; x < width; x++) get_pixel(x, y, row + 1 + 3 * x);
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    vector<unsigned char> comp(clen);
+    int status = -1;
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) == Z_OK) {
+        static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+        fwrite(sig, 1, 8, fp);
+        unsigned char ihdr[13] = {(unsigned char)(width >> 24), (unsigned char)(width >> 16), (unsigned char)(width >> 8), (unsigned char)width,
+                                  (unsigned char)(height >> 24), (unsigned char)(height >> 16), (unsigned char)(height >> 8), (unsigned char)height,
+                                  8, 2, 0, 0, 0};
+        png_chunk(fp, "IHDR", ihdr, 13);
+        png_chunk(fp, "IDAT", comp.data(), clen);
+        png_chunk(fp, "IEND", nullptr, 0);
+        status = ferror(fp) ? -1 : 0;
+    }
+    if (fclose(fp) != 0) status = -1;
+    return status;
+}
+
+/* -------------------------------------------------------------- integrator */
+
+static void fill_camera(pt_camera& c, const Scene* s) {
+    for (int k = 0; k < 3; k++) {
+        c.origin[k] = s->main_camera.origin(k); c.direction[k] = s->main_camera.direction(k);
+        c.up[k] = s->scene_up(k); c.sky_color[k] = s->sky_color(k);
+    }
+    c.image_plane_width = s->camera_image_plane_width;
+    c.plane_of_focus_distance = s->plane_of_focus_distance;
+    c.dof_dispersion = s->dof_dispersion;
+}
+
+static void fill_lights(vector<pt_light>& out, const Scene* s) {
+    out.clear();
+    if (!s->lights) return;
+    for (const Light& l : *s->lights) {
+        pt_light p;
+        for (int k = 0; k < 3; k++) { p.position[k] = l.position(k); p.color[k] = l.color(k); }
+        out.push_back(p);
+    }
+}
+
+static double now_seconds() {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec + tv.tv_usec * 1e-6;
+}
+
+Integrator::Integrator(int width, int height, Scene* _scene, int _device)
+    : scene(_scene), passes(0), last_pass_seconds(0), seed(1), device(_device), film(nullptr), next_sample(0) {
+    canvas = new Canvas(width, height);
+    canvas->zero();
+    pt_scene* ds = scene && scene->tree ? scene->tree->device_scene(device) : nullptr;
+    if (ds && pt_film_create(ds, width, height, nullptr, &film) != PT_OK) film = nullptr;
+    if (!film) cerr << "Integrator: no GPU film (" << pt_last_error() << ")" << endl;
+}
+
+Integrator::~Integrator() {
+    if (film) pt_film_destroy(film);
+    delete canvas;
+}
+
+Ray Integrator::get_ray_for_pixel(int x, int y) { /* integrator.cpp:197-209 */
+    Vec camera_right = scene->main_camera.direction.cross(scene->scene_up);
+    camera_right.normalize();
+    Vec camera_up = camera_right.cross(scene->main_camera.direction);
+    camera_up.normalize();
+    Real aspect_ratio = canvas->height / (Real)canvas->width;
+    Real dx = scene->camera_image_plane_width * (x - canvas->width / 2) / (Real)canvas->width;
+    Real dy = -scene->camera_image_plane_width * (y - canvas->height / 2) * aspect_ratio / (Real)canvas->height;
+    Vec offset = camera_right * dx + camera_up * dy;
+    return Ray(scene->main_camera.origin, scene->main_camera.direction + offset);
+}
+
+/* One pass over the rectangle on this integrator's GPU, then the film is copied back so that
+ * canvas reflects it (callers such as interactive.cpp read canvas right after perform_pass). */
+void Integrator::perform_pass(PassDescriptor desc) {
+    if (!film) return;
+    double t0 = now_seconds();
+    pt_camera cam;
+    fill_camera(cam, scene);
+    vector<pt_light> lights;
+    fill_lights(lights, scene);
+    pt_tile_pass p = {desc.start_x, desc.start_y, desc.width, desc.height, next_sample++, 1};
+    pt_render_stats st;
+    if (pt_render_passes(film, &cam, lights.data(), (int)lights.size(), &p, 1, seed, &st) == PT_OK) {
+        __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
+        download();
+    }
+    last_pass_seconds = now_seconds() - t0;
+    passes++;
+}
+
+int Integrator::download() {
+    if (!film) return -1;
+    vector<float> rgb((size_t)canvas->size * 3);
+    if (pt_film_read(film, rgb.data(), canvas->per_pixel_passes) != PT_OK) return -1;
+    for (int i = 0; i < canvas->size; i++) canvas->pixels[i] = Vec(rgb[3 * (size_t)i], rgb[3 * (size_t)i + 1], rgb[3 * (size_t)i + 2]);
+    return 0;
+}
+
+/* ----------------------------------------------------------- render engine */
+
+RenderThread::RenderThread(RenderEngine* _parent, int device) : parent(_parent), is_running(false) {
+    pthread_mutex_init(&integrator_lock, NULL);
+    integrator = new Integrator(parent->width, parent->height, parent->scene, device);
+    integrator->seed = parent->seed;
+    pthread_create(&thread, nullptr, RenderThread::render_thread_main, (void*)this);
+}
+
+RenderThread::~RenderThread() {
+    pthread_mutex_destroy(&integrator_lock);
+    delete integrator;
+}
+
+void RenderThread::send_message(RenderMessage message) {
+    pthread_mutex_lock(&parent->messages_lock);
+    parent->messages.push_back(message);
+    pthread_mutex_unlock(&parent->messages_lock);
+    sem_post(&parent->messages_semaphore);
+}
+
+void RenderThread::kill_immediately() { send_message(RenderMessage({true, PassDescriptor(), 0})); }
+
+void* RenderThread::render_thread_main(void* cookie) {
+    RenderThread* self = (RenderThread*)cookie;
+    RenderEngine* eng = self->parent;
+    const size_t max_batch = 65536;
+    vector<pt_tile_pass> batch;
+    vector<pt_light> lights;
+    while (true) {
+        sem_wait(&eng->messages_semaphore);
+        bool die = false;
+        batch.clear();
+        pthread_mutex_lock(&eng->messages_lock);
+        /* The message that woke us, then further ones already queued (each has a semaphore count
+         * of its own, consumed with sem_trywait): this worker's share of the queue, but at
+         * least about a thousand tile passes so that a batch keeps the GPU busy. */
+        size_t queued = eng->messages.size(), n_workers = max<size_t>(eng->workers.size(), 1);
+        size_t take = max((queued + n_workers - 1) / n_workers, min<size_t>(queued, 1024));
+        take = min(take, max_batch);
+        while (true) {
+            if (eng->messages.empty()) break; /* queue was cleared by kill_workers */
+            RenderMessage m = eng->messages.front();
+            if (m.do_die) {
+                if (batch.empty()) { eng->messages.pop_front(); die = true; }
+                else sem_post(&eng->messages_semaphore); /* leave it queued: render what we hold first */
+                break;
+            }
+            eng->messages.pop_front();
+            batch.push_back({m.desc.start_x, m.desc.start_y, m.desc.width, m.desc.height, m.sample, 1});
+            if (batch.size() >= take || sem_trywait(&eng->messages_semaphore) != 0) break;
+        }
+        pthread_mutex_unlock(&eng->messages_lock);
+        if (die) break;
+        if (batch.empty()) continue;
+
+        self->is_running = true;
+        self->currently_processing.start_x = batch[0].x; self->currently_processing.start_y = batch[0].y;
+        self->currently_processing.width = batch[0].w; self->currently_processing.height = batch[0].h;
+        pthread_mutex_lock(&self->integrator_lock);
+        Integrator* in = self->integrator;
+        double t0 = now_seconds();
+        if (in->film) {
+            pt_camera cam;
+            fill_camera(cam, eng->scene); /* camera and lights are re-read for every batch */
+            fill_lights(lights, eng->scene);
+            pt_render_stats st;
+            int rc = pt_render_passes(in->film, &cam, lights.data(), (int)lights.size(), batch.data(), (int)batch.size(), eng->seed, &st);
+            if (rc == PT_OK) __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
+            else cerr << "render worker: " << pt_last_error() << endl;
+        }
+        in->last_pass_seconds = now_seconds() - t0;
+        in->passes += (int)batch.size();
+        pthread_mutex_unlock(&self->integrator_lock);
+        self->is_running = false;
+
+        pthread_mutex_lock(&eng->master_lock);
+        eng->total_passes_completed += (int)batch.size();
+        pthread_mutex_unlock(&eng->master_lock);
+        for (size_t i = 0; i < batch.size(); i++) sem_post(&eng->passes_semaphore);
+    }
+    return nullptr;
+}
+
+RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_width), height(_height), scene(_scene), seed(1) {
+    sem_init(&passes_semaphore, 0, 0);
+    pthread_mutex_init(&master_lock, NULL);
+    sem_init(&messages_semaphore, 0, 0);
+    pthread_mutex_init(&messages_lock, NULL);
+    master_canvas = new Canvas(width, height);
+    tile_width = width;
+    tile_height = height;
+    total_passes_issued = 0;
+    total_passes_completed = 0;
+    semaphore_passes_pending = 0;
+    int n = get_optimal_thread_count();
+    for (int i = 0; i < n; i++) workers.push_back(new RenderThread(this, i));
+    if (workers.empty()) cerr << "RenderEngine: no GPU available (" << pt_last_error() << ")" << endl;
+}
+
+RenderEngine::~RenderEngine() {
+    sync();
+    for (auto worker : workers) worker->send_message(RenderMessage({true, PassDescriptor(), 0}));
+    for (auto worker : workers) pthread_join(worker->thread, nullptr);
+    for (auto worker : workers) delete worker;
+    sem_destroy(&passes_semaphore);
+    pthread_mutex_destroy(&master_lock);
+    sem_destroy(&messages_semaphore);
+    pthread_mutex_destroy(&messages_lock);
+    delete master_canvas;
+}
+
+void RenderEngine::issue_pass_desc(PassDescriptor desc) {
+    if (workers.empty()) return;
+    PassDescriptor key = desc;
+    key.clamp_bounds(width, height);
+    uint32_t sample = samples_issued[make_pair(make_pair(key.start_x, key.start_y), make_pair(key.width, key.height))]++;
+    int worker = (total_passes_issued++) % (int)workers.size();
+    workers[(size_t)worker]->send_message(RenderMessage({false, desc, sample}));
+    semaphore_passes_pending++;
+}
+
+void RenderEngine::perform_full_pass() {
+    for (int next_y = 0; next_y < height; next_y += tile_height)
+        for (int next_x = 0; next_x < width; next_x += tile_width)
+            issue_pass_desc(PassDescriptor(next_x, next_y, tile_width, tile_height));
+}
+
+static Real global_tile_center_x, global_tile_center_y;
+static inline Real square(Real x) { return x * x; }
+static bool tile_compare(const pair<int, int>& a, const pair<int, int>& b) {
+    Real a_distance = square(a.first - global_tile_center_x) + square(a.second - global_tile_center_y);
+    Real b_distance = square(b.first - global_tile_center_x) + square(b.second - global_tile_center_y);
+    return a_distance < b_distance;
+}
+
+void RenderEngine::perform_full_passes(int pass_count) { /* integrator.cpp:428-449: centre-out order */
+    vector<pair<int, int>> tile_spots;
+    for (int next_y = 0; next_y < height; next_y += tile_height)
+        for (int next_x = 0; next_x < width; next_x += tile_width)
+            for (int j = 0; j < pass_count; j++) tile_spots.push_back(pair<int, int>(next_x, next_y));
+    global_tile_center_x = (width - tile_width) / 2.0;
+    global_tile_center_y = (height - tile_height) / 2.0;
+    stable_sort(tile_spots.begin(), tile_spots.end(), tile_compare);
+    for (auto spot : tile_spots) issue_pass_desc(PassDescriptor(spot.first, spot.second, tile_width, tile_height));
+}
+
+void RenderEngine::sync() {
+    while (semaphore_passes_pending) {
+        semaphore_passes_pending--;
+        sem_wait(&passes_semaphore);
+    }
+}
+
+/* Drops every pass that has not started yet and stops the workers; passes already on a GPU
+ * finish first.  No more passes may be issued afterwards. */
+void RenderEngine::kill_workers() {
+    pthread_mutex_lock(&messages_lock);
+    messages.clear();
+    pthread_mutex_unlock(&messages_lock);
+    for (auto worker : workers) worker->kill_immediately();
+    for (auto worker : workers) pthread_join(worker->thread, nullptr);
+    for (auto worker : workers) delete worker;
+    workers.clear();
+    semaphore_passes_pending = 0;
+}
+
+/* Sums the workers' films into master_canvas (Canvas::add_from per worker, as the reference
+ * does) after copying each GPU's film to the host.  May be called while workers run: each
+ * film is read between two batches. */
+int RenderEngine::rebuild_master_canvas() {
+    master_canvas->zero();
+    int total_passes = 0;
+    for (auto worker : workers) {
+        pthread_mutex_lock(&worker->integrator_lock);
+        worker->integrator->download();
+        master_canvas->add_from(worker->integrator->canvas);
+        total_passes += worker->integrator->passes;
+        pthread_mutex_unlock(&worker->integrator_lock);
+    }
+    return total_passes;
+}
+
+void RenderEngine::zero() {
+    sync();
+    total_passes_issued = 0;
+    total_passes_completed = 0;
+    for (auto worker : workers) {
+        if (worker->integrator->film) pt_film_zero(worker->integrator->film);
+        worker->integrator->canvas->zero();
+    }
+}
+
+/* ------------------------------------------------------------ progress bar */
+
+ProgressBar::ProgressBar(RenderEngine* _engine) : engine(_engine) {
+    start = new struct timeval;
+    gettimeofday(start, NULL);
+}
+ProgressBar::~ProgressBar() { delete start; }
+bool ProgressBar::init() { return true; }
+
+void ProgressBar::main_loop() { /* visualizer.cpp:152-179 */
+    int completed, issued;
+    double elapsed;
+    do {
+        struct timeval stop, result;
+        gettimeofday(&stop, NULL);
+        timersub(&stop, start, &result);
+        elapsed = result.tv_sec + result.tv_usec * 1e-6;
+        pthread_mutex_lock(&engine->master_lock);
+        completed = engine->total_passes_completed;
+        pthread_mutex_unlock(&engine->master_lock);
+        issued = engine->total_passes_issued;
+        double completion = issued ? completed / (double)issued : 1.0;
+        double total_time = elapsed / real_max(1e-4, completion);
+        double remaining = total_time - elapsed;
+        string str_elapsed = format_seconds_as_hms(elapsed, 7);
+        string str_remaining = format_seconds_as_hms(remaining, 7);
+        string str_total_time = format_seconds_as_hms(total_time, 7);
+        printf("\r[\033[93m%6.2f%%\033[0m] \033[94mElapsed:\033[0m %s   \033[94mRemaining:\033[0m %s   \033[94mTotal:\033[0m %s   \033[94mTile samples:\033[0m %i/%i",
+               100.0 * completion, str_elapsed.c_str(), str_remaining.c_str(), str_total_time.c_str(), completed, issued);
+        fflush(stdout);
+        if (completed < issued) usleep(engine->workers.empty() ? 0 : 50000);
+        if (engine->workers.empty()) break;
+    } while (completed < issued);
+    double performance = rays_cast / real_max(1e-9, elapsed);
+    printf(" \033[92mDone!\033[0m Perf: %.1fMr/s\n", performance * 1e-6);
+}

@@ -4,7 +4,7 @@
 for d in variants/*/; do
   name=$(basename $d)
   echo -n "$name: "
-  PT_HIP_LIB=$PWD/$d/libpt_hip.so timeout -k 10 120 python3 scripts/raycast_bench.py --reps 5 "$@" 2>&1 | tail -1 | python3 -c "
+  PT_HIP_LIB=$PWD/$d/libpt_hip.so timeout -k 10 120 python3 scripts/raycast_bench.py --reps 3 --width 3840 --height 2160 --sphere-rays 8388608 "$@" 2>&1 | tail -1 | python3 -c "
 import sys, json
 try:
     r = json.loads(sys.stdin.read())

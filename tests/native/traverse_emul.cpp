@@ -103,3 +103,28 @@ int emul_raycast_shadow(const pt_flat_scene* sc, uint64_t n, const float* o, con
 }
 
 } // extern "C"
+
+/* Step sequence of one ray through the lane state machine, one byte per step:
+ * 'T' triangle, 'N' interior node, 'P' pop.  Returns the length (or -1 if cap is too small).
+ * Used to study wave scheduling policies offline. */
+extern "C" int emul_step_trace(const pt_flat_scene* sc, const float* o, const float* d, char* out, int cap) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    ptc::Lane L;
+    L.r.ox = o[0]; L.r.oy = o[1]; L.r.oz = o[2];
+    L.r.dx = d[0]; L.r.dy = d[1]; L.r.dz = d[2];
+    ptc::ray_set_recip(L.r);
+    CpuStack st;
+    int n = 0;
+    if (sc->n_tris == 0) return 0;
+    ptc::lane_start(L, sc->root_ref, root_of(sc), true);
+    while (!ptc::lane_finished(L)) {
+        if (n >= cap) return -1;
+        if (ptc::lane_has_leaf(L)) { ptc::TriData tr; mem.load_tri(L.leaf_pos, tr); ptc::lane_tri<false>(L, tr); out[n++] = 'T'; }
+        else if (ptc::lane_has_node(L)) {
+            ptc::NodeData nd; mem.load_node(L.cur, nd);
+            if (L.tame) ptc::lane_node<false, true>(L, nd, st); else ptc::lane_node<false, false>(L, nd, st);
+            out[n++] = 'N';
+        } else { ptc::lane_pop<false>(L, st); out[n++] = 'P'; }
+    }
+    return n;
+}

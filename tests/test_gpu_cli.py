@@ -1,0 +1,53 @@
+"""The drop-in front end: cli_render (reference flags) through the C++ Scene/RenderEngine API
+on the GPU, checked against the CPU oracle's image.  BASELINE.json configs[0] geometry:
+~1k-triangle STL, 320x240, 16 spp."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, orc, pta
+
+pytestmark = pytest.mark.gpu
+
+CLI = os.path.join(ROOT, "path_tracing_amd", "bin", "cli_render")
+
+
+def _read_png(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def test_cli_render_matches_oracle(tmp_path, scene_small):
+    stl = str(tmp_path / "standin.stl")
+    out = str(tmp_path / "out.png")
+    pta.meshgen.write_stl(stl, scene_small.tris)
+    W, H, S = 320, 240, 16
+    cmd = [CLI, stl, "--output", out, "--width", str(W), "--height", str(H), "--samples", str(S),
+           "--dof-aperture", "0.1", "--dof-distance", "4.5", "--seed", "4"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Read in %d triangles." % scene_small.oracle.n in res.stdout
+    assert "Wrote to: " + out in res.stdout
+    assert "input        = " + stl in res.stdout and "samples      = 16" in res.stdout
+    img = _read_png(out)
+    assert img.shape == (H, W, 3)
+    # the oracle renders the same sample indices: tiles are 64x64, every tile gets samples 0..15
+    cam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    rgb, passes, _ = scene_small.oracle.render(cam, orc.cli_lights(), W, H, None, 0, S, seed=4)
+    assert (passes == S).all()
+    want = orc.tonemap(rgb, passes).reshape(H, W, 3)
+    diff = np.abs(img.astype(int) - want.astype(int))
+    # sums differ in the last float bits (bounce terms are added in another order), which can
+    # move a value across an 8-bit truncation boundary
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_cli_errors(tmp_path):
+    res = subprocess.run([CLI], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1 and "No input STL specified." in res.stdout
+    res = subprocess.run([CLI, str(tmp_path / "missing.stl")], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1 and "Couldn't read input file." in res.stdout
+    res = subprocess.run([CLI, "--help"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1 and "--camera-altitude" in res.stdout and "--tile-width" in res.stdout
