@@ -162,6 +162,7 @@ def main():
             "camera_samples_per_s": round(samples_all / elapsed, 1),
             "wall_s_1080p_1000spp_extrapolated": round(elapsed / samples_all * 1920 * 1080 * 1000, 2),
             "rays_per_sample": round(rays_all / samples_all, 4),
+            "closest_rays": int(closest_all), "shadow_rays": int(shadow_all), "camera_samples": int(samples_all),
             "film_check": film_ok,
             "scene_prepare_s": round(t_prepare, 2),
             "kernel_ms": {name: {"ms": round(kt[c][0], 3), "launches": kt[c][1]} for c, name in

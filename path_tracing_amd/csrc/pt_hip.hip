@@ -146,8 +146,10 @@ struct TraceArgs {
     const uint32_t* d_count; /* number of work items = *d_count * count_mul, in device memory */
     uint32_t count_mul;
     uint32_t* d_next_chunk;  /* 8 atomic chunk counters (one per queue region), zero at launch */
-    int32_t* out_idx;
+    int32_t* out_idx;        /* CLOSEST_MESH: four separate arrays (the C ABI's layout) */
     float *out_t, *out_u, *out_v;
+    float4* out_hit;         /* CLOSEST_FLAT: one 16-byte record {position bits, t, u, v} per ray, so a
+                                retiring lane issues one store instead of four partial-line writes */
     const float* dist;       /* shadow modes */
     uint8_t* vis;            /* shadow modes */
     uint32_t* defer_list;    /* SHADOW_ANY appends ray indices here, SHADOW_EXACT reads them */
@@ -286,10 +288,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         if (active && lane_finished(L)) {
             const uint32_t i = (uint32_t)ray;
             if (CLOSEST_OUT) {
-                a.out_idx[i] = L.found ? (int32_t)(MODE == TRACE_CLOSEST_MESH ? L.best.mesh : L.best.tri) : -1;
-                a.out_t[i] = L.found ? L.best.t : 0.0f;
-                a.out_u[i] = L.found ? L.best.u : 0.0f;
-                a.out_v[i] = L.found ? L.best.v : 0.0f;
+                if (MODE == TRACE_CLOSEST_FLAT) {
+                    float4 h;
+                    h.x = __uint_as_float(L.found ? L.best.tri : 0xffffffffu);
+                    h.y = L.found ? L.best.t : 0.0f; h.z = L.found ? L.best.u : 0.0f; h.w = L.found ? L.best.v : 0.0f;
+                    a.out_hit[i] = h;
+                } else {
+                    a.out_idx[i] = L.found ? (int32_t)L.best.mesh : -1;
+                    a.out_t[i] = L.found ? L.best.t : 0.0f;
+                    a.out_u[i] = L.found ? L.best.u : 0.0f;
+                    a.out_v[i] = L.found ? L.best.v : 0.0f;
+                }
             } else if (MODE == TRACE_SHADOW_ANY) {
                 a.vis[i] = L.found ? 0 : 1;
             } else {
@@ -345,8 +354,7 @@ struct RenderBuffers {
     RaySoAW q[2];
     uint32_t* qpath[2];
     /* hits of the current queue */
-    int32_t* hit_tri;
-    float *hit_t, *hit_u, *hit_v;
+    float4* hit; /* {leaf-order position bits or ~0, t, u, v} */
     /* per path */
     uint32_t *pixel, *sample;
     float *rad_r, *rad_g, *rad_b, *thr;
@@ -457,9 +465,11 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
         bool hit = false;
         uint32_t path = 0;
         int32_t tri = -1;
+        float4 hrec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (i < n) {
             path = b.qpath[cur][i];
-            tri = b.hit_tri[i];
+            hrec = b.hit[i];
+            tri = (int32_t)__float_as_uint(hrec.x);
             hit = tri >= 0;
             if (!hit) { /* sky, reference integrator.cpp:153 */
                 float thr = b.thr[path];
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             st.base_n = v3(s1.x, s1.y, s1.z); st.u_n = v3(s2.x, s2.y, s2.z); st.v_n = v3(s3.x, s3.y, s3.z);
             V3f o = v3(b.q[cur].ox[i], b.q[cur].oy[i], b.q[cur].oz[i]);
             V3f d = v3(b.q[cur].dx[i], b.q[cur].dy[i], b.q[cur].dz[i]);
-            SurfaceFrame f = surface_frame(o, d, b.hit_t[i], b.hit_u[i], b.hit_v[i], st);
+            SurfaceFrame f = surface_frame(o, d, hrec.y, hrec.z, hrec.w, st);
             float thr = b.thr[path];
             uint32_t pixel = b.pixel[path], sample = b.sample[path];
             for (uint32_t l = 0; l < n_lights; l++) {
@@ -953,8 +963,8 @@ static int film_ensure_scratch(pt_film* f, size_t paths, uint32_t n_lights, size
         for (int c = 0; c < 6 && !rc; c++) rc = film_alloc(f, q[c], P);
         if (!rc) rc = film_alloc(f, &b.qpath[k], P);
     }
-    if (!rc) rc = film_alloc(f, &b.hit_tri, P);
-    float** per_path[8] = {&b.hit_t, &b.hit_u, &b.hit_v, &b.rad_r, &b.rad_g, &b.rad_b, &b.thr, nullptr};
+    if (!rc) rc = film_alloc(f, &b.hit, P);
+    float** per_path[8] = {&b.rad_r, &b.rad_g, &b.rad_b, &b.thr, nullptr, nullptr, nullptr, nullptr};
     for (int c = 0; per_path[c] && !rc; c++) rc = film_alloc(f, per_path[c], P);
     if (!rc) rc = film_alloc(f, &b.pixel, P);
     if (!rc) rc = film_alloc(f, &b.sample, P);
@@ -1012,7 +1022,7 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
         a.rays = {b.q[cur].ox, b.q[cur].oy, b.q[cur].oz, b.q[cur].dx, b.q[cur].dy, b.q[cur].dz};
         a.d_count = b.cnt + CNT_QUEUE + depth;
         a.d_next_chunk = b.cnt + CNT_CHUNK(0, depth);
-        a.out_idx = b.hit_tri; a.out_t = b.hit_t; a.out_u = b.hit_u; a.out_v = b.hit_v;
+        a.out_hit = b.hit;
         int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a);
         if (rc) return rc;
         {

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Derives profiles/traffic.json from a scripts/profile_round.sh output directory.
+
+HBM-side bytes of the closest-hit trace kernel per ray = (2 * FETCH_SIZE + WRITE_SIZE) / rays,
+where FETCH_SIZE and WRITE_SIZE are the rocprofv3 counters (kilobytes) summed over every
+dispatch of k_trace<1> in their own PMC passes, FETCH_SIZE doubled as the gfx950 correction for
+16-byte-per-lane loads prescribes, and rays = closest rays per step * (steps + warmup) of the
+profiled bench command (taken from its JSON line).
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def counter_sum(root, counter, kernel):
+    for path in glob.glob(os.path.join(root, "pmc*", "*.db")):
+        db = sqlite3.connect(path)
+        try:
+            row = db.execute("select sum(value), count(distinct dispatch_id) from counters_collection "
+                             "where counter_name=? and kernel_name like ?", (counter, "%" + kernel + "%")).fetchone()
+        except sqlite3.Error:
+            row = None
+        db.close()
+        if row and row[0]:
+            return float(row[0]), int(row[1])
+    return None, 0
+
+
+def main():
+    root = sys.argv[1]
+    line = json.loads(open(os.path.join(root, "bench_line_under_profiler.json")).read().strip().splitlines()[-1])
+    steps_total = line["steps"] + line["warmup"]
+    out = {"source": os.path.basename(root.rstrip("/")), "bench_line": {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}}
+    for name, kernel, key in (("closest", "k_trace<1>", "closest_rays"), ("shadow", "k_trace<2>", "shadow_rays")):
+        rays = line[key] / line["steps"] * steps_total
+        fetch_kb, nd = counter_sum(root, "FETCH_SIZE", kernel)
+        write_kb, _ = counter_sum(root, "WRITE_SIZE", kernel)
+        hit, _ = counter_sum(root, "TCC_HIT_sum", kernel)
+        miss, _ = counter_sum(root, "TCC_MISS_sum", kernel)
+        if fetch_kb is None or write_kb is None:
+            continue
+        out[name + "_dispatches"] = nd
+        out[name + "_rays"] = rays
+        out[name + "_fetch_bytes_per_ray_raw"] = fetch_kb * 1024.0 / rays
+        out[name + "_write_bytes_per_ray"] = write_kb * 1024.0 / rays
+        out[name + "_bytes_per_ray"] = (2.0 * fetch_kb + write_kb) * 1024.0 / rays
+        if hit and miss:
+            out[name + "_l2_hit_rate"] = hit / (hit + miss)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""Error behaviour and edge cases of the C ABI on the GPU box: bad input is rejected with an
+error code and message, never a fault."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import orc, pta
+from path_tracing_amd import native
+from path_tracing_amd.native import PtError
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat_copy(host):
+    nodes, tris, shade = host.flat_arrays()
+    f = host.flat
+    g = native.FlatScene()
+    g.n_nodes, g.n_tris, g.root_ref, g.max_depth = f.n_nodes, f.n_tris, f.root_ref, f.max_depth
+    g.root_min[:] = list(f.root_min)
+    g.root_max[:] = list(f.root_max)
+    return g, nodes, tris, shade
+
+
+def _create(g, nodes, tris, shade):
+    g.nodes = nodes.ctypes.data
+    g.tris = tris.ctypes.data
+    g.shade = shade.ctypes.data
+    h = C.c_void_p()
+    rc = native.hip_lib().pt_scene_create(0, C.byref(g), C.byref(h))
+    if rc == 0:
+        native.hip_lib().pt_scene_destroy(h)
+    return rc, native.hip_lib().pt_last_error().decode()
+
+
+def test_malformed_trees_are_rejected(scene_small):
+    g, nodes, tris, shade = _flat_copy(scene_small.host)
+    assert _create(g, nodes, tris, shade)[0] == 0
+    bad = nodes.copy()
+    bad["lo_ref"][3] = 10 ** 6                      # node index out of range
+    rc, msg = _create(g, bad, tris, shade)
+    assert rc == -1 and "out of range" in msg
+    bad = nodes.copy()
+    bad["hi_ref"][5] = 0                            # back edge to the root: not a tree
+    rc, msg = _create(g, bad, tris, shade)
+    assert rc in (-1, -4) and ("twice" in msg or "deeper" in msg)
+    bad = nodes.copy()
+    bad["axis"][0] = 7
+    assert _create(g, bad, tris, shade)[0] == -1
+    bad = nodes.copy()
+    bad["lo_ref"][0] = 0x80000000 | (9 << 26) | (scene_small.host.n - 2)   # leaf running past the array
+    rc, msg = _create(g, bad, tris, shade)
+    assert rc == -1 and "leaf" in msg
+    # device index out of range
+    h = C.c_void_p()
+    g.nodes, g.tris, g.shade = nodes.ctypes.data, tris.ctypes.data, shade.ctypes.data
+    assert native.hip_lib().pt_scene_create(99, C.byref(g), C.byref(h)) == -1
+
+
+def test_null_and_limit_arguments(scene_small):
+    L = native.hip_lib()
+    gpu = scene_small.gpu
+    assert L.pt_raycast_closest(gpu.h, 4, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.pt_raycast_closest(None, 4, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.pt_raycast_closest(gpu.h, 0, None, None, None, None, None, None, None, None, None, None) == 0
+    film = pta.Film(gpu, 32, 16)
+    cam = pta.cli_camera()
+    with pytest.raises(PtError):
+        film.render(cam, [((0, 0, 3), (1, 1, 1))] * 17, [(0, 0, -1, -1, 0, 1)])    # more than PT_MAX_LIGHTS
+    h = C.c_void_p()
+    assert L.pt_film_create(gpu.h, 0, 16, None, C.byref(h)) == -1
+    assert L.pt_film_create(gpu.h, -5, 16, None, C.byref(h)) == -1
+
+
+def test_render_edge_cases(scene_small):
+    sc = scene_small
+    W, H = 50, 37            # not multiples of 8: padded micro-tiles
+    cam_o = orc.cli_camera()
+    cam_o.sky_color[:] = [0.25, 0.5, 0.75]
+    cam_g = pta.cli_camera()
+    cam_g.sky_color[:] = [0.25, 0.5, 0.75]
+    film = pta.Film(sc.gpu, W, H)
+    # rectangles hanging over the edges are clamped like PassDescriptor::clamp_bounds; an empty
+    # pass list and zero samples are no-ops; no lights at all is legal
+    film.render(cam_g, [], [], seed=2)
+    film.render(cam_g, [], [(10, 5, 1000, 1000, 0, 2), (-3, -3, 20, 20, 0, 1), (0, 0, 8, 8, 5, 0)], seed=2)
+    rgb, passes = film.read()
+    want_rgb = np.zeros((H, W, 3), np.float32)
+    want_p = np.zeros((H, W), np.int32)
+    sc.oracle.render(cam_o, [], W, H, (10, 5, 1000, 1000), 0, 2, seed=2, rgb=want_rgb, passes=want_p)
+    sc.oracle.render(cam_o, [], W, H, (-3, -3, 20, 20), 0, 1, seed=2, rgb=want_rgb, passes=want_p)
+    assert np.array_equal(passes, want_p)
+    assert np.allclose(rgb, want_rgb, rtol=1e-5, atol=1e-6)
+    assert rgb[20, 30].sum() > 0      # sky colour or its mirror image reaches the film without lights
+
+
+def test_zero_then_reuse(scene_small):
+    film = pta.Film(scene_small.gpu, 24, 16)
+    cam = pta.cli_camera()
+    film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 2)], seed=1)
+    a, pa = film.read()
+    film.zero()
+    z, pz = film.read()
+    assert (z == 0).all() and (pz == 0).all()
+    film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 2)], seed=1)
+    b, pb = film.read()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(pa, pb)
