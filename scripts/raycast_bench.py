@@ -25,18 +25,22 @@ def main():
     ap.add_argument("--sets", default="primary,sphere,shadow")
     ap.add_argument("--sphere-rays", type=int, default=1 << 21)
     ap.add_argument("--check", action="store_true", help="compare a sample of results with the CPU oracle")
+    ap.add_argument("--check-emul", type=int, default=0, help="compare this many primary rays with the CPU lane emulation")
     args = ap.parse_args()
 
     import torch
     import path_tracing_amd as pta
 
     tris = pta.meshgen.standin_scene(args.level)
-    host = pta.HostScene(tris)
+    import time
+    t0 = time.time()
+    host = pta.HostScene(tris, threads=16)
+    t_host = time.time() - t0
     gpu = pta.GpuScene(host, 0)
     W, H = args.width, args.height
     n = W * H
     dev = "cuda"
-    res = {"triangles": host.n, "tree": host.tree_stats()}
+    res = {"triangles": host.n, "tree": host.tree_stats(), "host_prepare_s": round(t_host, 2), "host_timings": host.timings()}
 
     def soa(a):
         return [torch.from_numpy(np.ascontiguousarray(a[:, k])).to(dev) for k in range(3)]
@@ -78,6 +82,27 @@ def main():
             res["primary_check_bit_exact"] = bool(all(
                 np.array_equal(np.ascontiguousarray(g).view(np.uint32), np.ascontiguousarray(w).view(np.uint32))
                 for g, w in zip(got, want)))
+        if args.check_emul:
+            # Scenes too large for the CPU oracle: compare with the lane-level CPU emulation of
+            # the same device logic over the same flat arrays (tests/native/traverse_emul.cpp),
+            # which the CPU test-suite holds bit-exact against the oracle on smaller scenes.
+            import ctypes as C
+            E = C.CDLL(os.path.join(ROOT, "tests", "native", "_build", "libtraverse_emul.so"))
+            E.emul_raycast_closest.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 7
+            sel = np.random.default_rng(0).choice(n, args.check_emul, replace=False)
+            o = np.ascontiguousarray(np.stack([p.cpu().numpy()[sel] for p in prim[:3]], axis=1))
+            d = np.ascontiguousarray(np.stack([p.cpu().numpy()[sel] for p in prim[3:]], axis=1))
+            m = len(sel)
+            w_idx = np.empty(m, np.int32)
+            w_t, w_u, w_v = (np.empty(m, np.float32) for _ in range(3))
+            flat = host.flat
+            ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+            worst = E.emul_raycast_closest(C.byref(flat), m, ptr(o), ptr(d), ptr(w_idx), ptr(w_t), ptr(w_u), ptr(w_v), None)
+            got = [x.cpu().numpy()[sel] for x in out]
+            res["primary_check_vs_emulation_bit_exact"] = bool(all(
+                np.array_equal(np.ascontiguousarray(g).view(np.uint32), np.ascontiguousarray(w).view(np.uint32))
+                for g, w in zip(got, (w_idx, w_t, w_u, w_v))))
+            res["emulation_max_stack_dwords"] = int(worst)
     if "sphere" in sets:
         rng = np.random.default_rng(1234)
         m = args.sphere_rays
