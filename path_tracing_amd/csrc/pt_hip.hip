@@ -80,55 +80,66 @@ struct RaySoAW {
 #ifndef REFILL_MIN
 #define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
 #endif
-#ifndef TRACE_TRIS_PER_ROUND
-#define TRACE_TRIS_PER_ROUND 1 /* triangles of a pending leaf tested per round (1 or 2) */
-#endif
-#ifndef TRACE_REGIONS
-#define TRACE_REGIONS 1    /* queue regions (one head each), at most 8.  Measured: 8 regions keyed by
-                              XCD (blockIdx % 8 or HW_REG_XCC_ID) were 18-40 % SLOWER than one shared head */
-#endif
 #ifndef TRACE_WAVES_PER_EU
-#define TRACE_WAVES_PER_EU 5 /* register budget of the trace kernels: waves per SIMD the compiler must allow */
+#define TRACE_WAVES_PER_EU 6 /* register budget of the trace kernels: waves per SIMD the compiler must allow */
 #endif
-
-struct GpuMem {
-    const float4* nodes;
-    const float4* tris;
-    __device__ __forceinline__ void load_node(uint32_t i, NodeData& n) const {
-        const float4* p = nodes + (size_t)i * 4;
-        float4 a = p[0], b = p[1], c = p[2], d = p[3];
-        n.lo_min[0] = a.x; n.lo_min[1] = a.y; n.lo_min[2] = a.z;
-        n.lo_max[0] = a.w; n.lo_max[1] = b.x; n.lo_max[2] = b.y;
-        n.hi_min[0] = b.z; n.hi_min[1] = b.w; n.hi_min[2] = c.x;
-        n.hi_max[0] = c.y; n.hi_max[1] = c.z; n.hi_max[2] = c.w;
-        n.lo_ref = __float_as_uint(d.x); n.hi_ref = __float_as_uint(d.y); n.axis = __float_as_uint(d.z);
-    }
-    __device__ __forceinline__ void load_tri(uint32_t k, TriData& t) const {
-        const float4* p = tris + (size_t)k * 3;
-        float4 a = p[0], b = p[1], c = p[2];
-        t.p0x = a.x; t.p0y = a.y; t.p0z = a.z;
-        t.e1x = a.w; t.e1y = b.x; t.e1z = b.y;
-        t.e2x = b.z; t.e2y = b.w; t.e2z = c.x;
-        t.mesh_index = __float_as_uint(c.y); t.leaf_count = __float_as_uint(c.z);
-    }
-};
 
 /* Per-lane stack.  The first STACK_LDS entries live in LDS, dword-interleaved across the block
- * (entry i of thread t at word i*TRACE_BLOCK + t), so whatever the lanes' depths are, a wave's
- * 64 accesses fall in 64 different banks.  Deeper entries go to a per-thread column of a spill
- * buffer in HBM, interleaved the same way across the whole grid. */
+ * (entry i of thread t at word (i + STACK_PAD) * TRACE_BLOCK + t), so whatever the lanes' depths
+ * are, a wave's 64 accesses fall in 64 different banks.  STACK_PAD unused rows below entry 0 let
+ * a pop read "the top three entries" of a shallower stack without a bounds test.  Deeper entries
+ * go to a per-thread column of a spill buffer in HBM, interleaved the same way across the whole
+ * grid.  The common path touches LDS only: the spill path is kept in separate blocks that wait
+ * for their own loads, so that a pop never has to wait for the round's outstanding global loads. */
+#define STACK_PAD 2
 struct LaneStack {
-    uint32_t* lds;    /* &stk[threadIdx.x] */
+    uint32_t* lds;    /* &stk[STACK_PAD * TRACE_BLOCK + threadIdx.x]: entry 0 of this lane */
     uint32_t* spill;  /* &spill[global thread id] */
     uint32_t stride;  /* threads in the grid */
+    __device__ __forceinline__ uint32_t slow_read(int i) const {
+        if (i < 0) return 0u;
+        if (i < STACK_LDS) return lds[i * TRACE_BLOCK];
+        return spill[(size_t)(i - STACK_LDS) * stride];
+    }
     __device__ __forceinline__ void push(int& sp, uint32_t v) {
-        if (sp < STACK_LDS) lds[sp * TRACE_BLOCK] = v;
+        if (__builtin_expect(sp < STACK_LDS, 1)) lds[sp * TRACE_BLOCK] = v;
         else spill[(size_t)(sp - STACK_LDS) * stride] = v;
         sp++;
     }
-    __device__ __forceinline__ uint32_t peek(int i) const {
-        i = i < 0 ? 0 : i;
-        return i < STACK_LDS ? lds[i * TRACE_BLOCK] : spill[(size_t)(i - STACK_LDS) * stride];
+    __device__ __forceinline__ void push_frame(int& sp, bool keep, uint32_t a, uint32_t b, uint32_t c) {
+        if (__builtin_expect(sp + 3 <= STACK_LDS, 1)) {
+            /* a is stored unconditionally and overwritten by b when it is not kept */
+            lds[sp * TRACE_BLOCK] = a;
+            sp += keep ? 1 : 0;
+            lds[sp * TRACE_BLOCK] = b;
+            lds[(sp + 1) * TRACE_BLOCK] = c;
+            sp += 2;
+        } else {
+            if (keep) push(sp, a);
+            push(sp, b);
+            push(sp, c);
+        }
+    }
+    __device__ __forceinline__ uint32_t peek1(int sp) const {
+        const int s = sp < STACK_LDS ? sp : STACK_LDS;
+        uint32_t e = lds[(s - 1) * TRACE_BLOCK];
+        if (__builtin_expect(sp > STACK_LDS, 0)) {
+            e = slow_read(sp - 1);
+            __builtin_amdgcn_s_waitcnt(0);   /* vmcnt(0) expcnt(0) lgkmcnt(0): the spill load is complete here */
+        }
+        return e;
+    }
+    __device__ __forceinline__ void peek3(int sp, uint32_t& e, uint32_t& w1, uint32_t& w2) const {
+        const int s = sp < STACK_LDS ? sp : STACK_LDS;   /* keeps the reads inside the LDS array */
+        e = lds[(s - 1) * TRACE_BLOCK];
+        w1 = lds[(s - 2) * TRACE_BLOCK];
+        w2 = lds[(s - 3) * TRACE_BLOCK];
+        if (__builtin_expect(sp > STACK_LDS, 0)) {
+            e = slow_read(sp - 1);
+            w1 = slow_read(sp - 2);
+            w2 = slow_read(sp - 3);
+            __builtin_amdgcn_s_waitcnt(0);   /* the spill loads are complete here */
+        }
     }
 };
 
@@ -145,7 +156,7 @@ struct TraceArgs {
     RaySoA rays;
     const uint32_t* d_count; /* number of work items = *d_count * count_mul, in device memory */
     uint32_t count_mul;
-    uint32_t* d_next_chunk;  /* 8 atomic chunk counters (one per queue region), zero at launch */
+    uint32_t* d_next_chunk;  /* atomic head of the ray queue, in chunks; zero at launch */
     int32_t* out_idx;        /* CLOSEST_MESH: four separate arrays (the C ABI's layout) */
     float *out_t, *out_u, *out_v;
     float4* out_hit;         /* CLOSEST_FLAT: one 16-byte record {position bits, t, u, v} per ray, so a
@@ -159,30 +170,33 @@ struct TraceArgs {
 
 /*
  * Persistent trace kernel.  Every wave loops over "rounds"; in a round each lane that holds a
- * ray advances it by one step of the lane state machine (traverse_core.h): either one triangle
- * of its pending leaf, or stack pops followed by one interior node.  The loads of a round
- * (triangle records, node records, and the rays of lanes being refilled) are issued before
- * any of them is consumed, so a round costs one memory round trip.  Lanes whose ray is
- * finished write their result and go idle; when enough lanes are idle the wave hands them the
- * next rays of its chunk (TRACE_CHUNK consecutive rays, one atomic on a queue head per chunk).
- * The queue is cut into 8 regions with a head each; a workgroup starts in region blockIdx % 8
- * (workgroups b and b+8 are observed to share an XCD, hence an L2) and moves on to the next
- * region when its own is empty, so neighbouring rays tend to meet in one L2 and no region is
- * left unserved.  The loop ends when every region is empty and every lane is idle, so the
- * grid always drains.
+ * ray advances it by one step of the lane state machine (traverse_core.h): one triangle of its
+ * pending leaf, or one interior node, followed by stack pops until it has a leaf or a node
+ * again (at most two per round).
+ *
+ * A round has ONE group of global loads, issued together at its top and consumed after all of
+ * them are in flight, so it costs one memory round trip:
+ *   - the rays of the lanes being refilled (consumed at the bottom of the round), and
+ *   - one 64-byte record per lane: the lane's next triangle (48 bytes used) or its interior
+ *     node, fetched through one per-lane address so that the same four load instructions
+ *     serve both kinds of lane.
+ * Stack traffic is LDS only on the common path and needs no wait on global memory.
+ *
+ * Lanes whose ray is finished write their result and go idle; when enough lanes are idle the
+ * wave hands them the next rays of its chunk (TRACE_CHUNK..16*TRACE_CHUNK consecutive rays,
+ * one atomic on the queue head per chunk).  The loop ends when the queue is empty and every
+ * lane is idle, so the grid always drains.
  */
 template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES_PER_EU))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY);
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
-    __shared__ uint32_t stk[STACK_LDS * TRACE_BLOCK];
+    __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
     const uint32_t n = *a.d_count * a.count_mul;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    GpuMem mem;
-    mem.nodes = sc.nodes; mem.tris = sc.tris;
     LaneStack st;
-    st.lds = stk + threadIdx.x;
+    st.lds = stk + STACK_PAD * TRACE_BLOCK + threadIdx.x;
     st.stride = gridDim.x * TRACE_BLOCK;
     st.spill = a.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
 
@@ -200,13 +214,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         while (chunk < 16u * TRACE_CHUNK && (uint64_t)chunk * 2u * 16u * waves <= n) chunk *= 2u;
     }
     const uint32_t total_chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
-    #ifdef TRACE_HOME_XCC
-    /* HW_REG_XCC_ID (hardware register 20, bits 3:0): the XCD this wave runs on */
-    const uint32_t home = ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % TRACE_REGIONS;
-#else
-    const uint32_t home = blockIdx.x % TRACE_REGIONS;
-#endif
-    uint32_t tried = 0;                   /* wave-uniform: regions found empty so far */
     const bool scene_tame = root_is_tame(sc.root);
 
     while (true) {
@@ -218,22 +225,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
                 if (pool_next >= pool_end) {
-                    exhausted = true;
-                    while (tried < (uint32_t)TRACE_REGIONS) {
-                        const uint32_t reg = (home + tried) % TRACE_REGIONS;
-                        const uint32_t lo = (uint32_t)(((uint64_t)reg * total_chunks) / TRACE_REGIONS);
-                        const uint32_t hi = (uint32_t)(((uint64_t)(reg + 1u) * total_chunks) / TRACE_REGIONS);
-                        uint32_t c = 0;
-                        if (lane == 0) c = atomicAdd(a.d_next_chunk + reg, 1u);
-                        c = __builtin_amdgcn_readfirstlane(c);
-                        if (c < hi - lo) {
-                            const uint64_t first = (uint64_t)(lo + c) * chunk;
-                            pool_next = (uint32_t)first;
-                            pool_end = (uint32_t)min((uint64_t)n, first + chunk);
-                            exhausted = false;
-                            break;
-                        }
-                        tried++;
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(a.d_next_chunk, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    if (c < total_chunks) {
+                        const uint64_t first = (uint64_t)c * chunk;
+                        pool_next = (uint32_t)first;
+                        pool_end = (uint32_t)min((uint64_t)n, first + chunk);
+                    } else {
+                        exhausted = true;
                     }
                 }
                 if (!exhausted) {
@@ -245,45 +245,59 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             }
             if (exhausted && idle == ~0ull) break;
         }
-        Ray9 nr;
-        float ndist = 0.0f;
-        if (starting) {
-            if (MODE == TRACE_SHADOW_EXACT) new_ray = a.defer_list[new_ray];
-            if (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_EXACT) ndist = a.dist[new_ray];
-            nr.ox = a.rays.ox[new_ray]; nr.oy = a.rays.oy[new_ray]; nr.oz = a.rays.oz[new_ray];
-            nr.dx = a.rays.dx[new_ray]; nr.dy = a.rays.dy[new_ray]; nr.dz = a.rays.dz[new_ray];
-        }
-
-        /* ---- this round's loads: triangle records first, then (after the pops) node records ---- */
+        /* ---- this round's loads ----
+         * The record of every lane that holds a ray: its next triangle, or its interior node. */
         const bool active = ray >= 0;
         const bool do_tri = active && lane_has_leaf(L);
-        TriData tr;
-        if (do_tri) mem.load_tri(L.leaf_pos, tr);
-#if TRACE_TRIS_PER_ROUND >= 2
-        /* second triangle of the same leaf in the same round, when the leaf is known to have one */
-        const bool do_tri2 = do_tri && L.leaf_end != PT_LEAF_UNKNOWN && L.leaf_pos + 1u < L.leaf_end;
-        TriData tr2;
-        if (do_tri2) mem.load_tri(L.leaf_pos + 1u, tr2);
-#endif
-        if (active && !do_tri && !lane_has_node(L) && L.sp > 0) {
+        const bool do_node = active && !do_tri && lane_has_node(L);
+        float4 q0, q1, q2, q3;   /* meaningful only in lanes with do_tri / do_node */
+        if (do_tri || do_node) {
+            const float4* rec = do_tri ? sc.tris + (size_t)L.leaf_pos * 3 : sc.nodes + (size_t)L.cur * 4;
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+            if (do_node) q3 = rec[3];
+        }
+        /* The rays of the lanes being refilled.  A starting lane is idle, so its ray registers
+         * are dead: the new ray is loaded straight into them. */
+        if (starting) {
+            if (MODE == TRACE_SHADOW_EXACT) new_ray = a.defer_list[new_ray];
+            if (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_EXACT) dist = a.dist[new_ray];
+            L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
+            L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
+        }
+        /* The round's single wait: every register a load above may have targeted is named as an
+         * input of an empty statement, so the loads are complete from here on along every
+         * control path, and nothing below or in the next round waits on global memory again. */
+        asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                           "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist));
+
+        /* ---- one step per lane ---- */
+        if (do_tri) {
+            TriData tr;
+            tr.p0x = q0.x; tr.p0y = q0.y; tr.p0z = q0.z;
+            tr.e1x = q0.w; tr.e1y = q1.x; tr.e1z = q1.y;
+            tr.e2x = q1.z; tr.e2y = q1.w; tr.e2z = q2.x;
+            tr.mesh_index = __float_as_uint(q2.y); tr.leaf_count = __float_as_uint(q2.z);
+            lane_tri<ANY>(L, tr);
+        }
+        {
+            NodeData nd;
+            nd.lo_min[0] = q0.x; nd.lo_min[1] = q0.y; nd.lo_min[2] = q0.z;
+            nd.lo_max[0] = q0.w; nd.lo_max[1] = q1.x; nd.lo_max[2] = q1.y;
+            nd.hi_min[0] = q1.z; nd.hi_min[1] = q1.w; nd.hi_min[2] = q2.x;
+            nd.hi_max[0] = q2.y; nd.hi_max[1] = q2.z; nd.hi_max[2] = q2.w;
+            nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
+            if (__any(do_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
+                if (do_node) lane_node<ANY, false>(L, nd, st);
+            } else {
+                if (do_node) lane_node<ANY, true>(L, nd, st);
+            }
+        }
+        /* ---- lanes left with neither a leaf nor a node take their next one from the stack ---- */
+        if (active && !lane_has_leaf(L) && !lane_has_node(L) && L.sp > 0) {
             lane_pop<ANY>(L, st);
             if (!lane_has_node(L) && !lane_has_leaf(L) && L.sp > 0) lane_pop<ANY>(L, st);
         }
-        const bool do_node = active && !do_tri && lane_has_node(L);
-        NodeData nd;
-        if (do_node) mem.load_node(L.cur, nd);
-
-        /* ---- one step per lane ---- */
-        if (do_tri) lane_tri<ANY>(L, tr);
-#if TRACE_TRIS_PER_ROUND >= 2
-        if (do_tri2 && lane_has_leaf(L)) lane_tri<ANY>(L, tr2);
-#endif
-        if (__any(do_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
-            if (do_node) lane_node<ANY, false>(L, nd, st);
-        } else {
-            if (do_node) lane_node<ANY, true>(L, nd, st);
-        }
-
         /* ---- retire finished rays ---- */
         if (active && lane_finished(L)) {
             const uint32_t i = (uint32_t)ray;
@@ -313,13 +327,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             /* Every hit has v <= 1, so with dist >= 1 the reference's test `v > dist` fails for any
              * hit and the answer is hit/no-hit.  Nearer lights need the closest hit's v: those rays
              * are queued for the exact pass. */
-            if (MODE == TRACE_SHADOW_ANY && !(ndist >= 1.0f)) defer = true;
+            if (MODE == TRACE_SHADOW_ANY && !(dist >= 1.0f)) defer = true;
             else {
-                L.r = nr;
                 ray_set_recip(L.r);
                 lane_start(L, sc.root_ref, sc.root, scene_tame);
                 ray = (int32_t)new_ray;
-                dist = ndist;
             }
         }
         if (MODE == TRACE_SHADOW_ANY) {

@@ -243,8 +243,11 @@ PT_HD uint32_t ref_leaf_count(uint32_t ref) { return (ref >> PT_REF_COUNT_SHIFT)
  *   interior node  (cur != NONE)           -> lane_node() with that node
  *   neither, stack not empty               -> lane_pop()
  *   neither, stack empty                   -> finished
- * Stack supplies push(int& sp, uint32_t), which advances the lane's stack pointer, and
- * peek(int index), which reads entry `index` (any value for index < 0); it is private to the lane.
+ * Stack is private to the lane and supplies
+ *   push(int& sp, v)                         store v at entry sp, advance sp
+ *   push_frame(int& sp, keep, a, b, c)       push a (only if keep), then b, then c
+ *   peek1(sp)                                entry sp-1
+ *   peek3(sp, e, w1, w2)                     entries sp-1, sp-2, sp-3 (any value below entry 0)
  */
 struct Lane {
     Ray9 r;
@@ -290,45 +293,68 @@ template <bool ANYHIT, class Stack>
 PT_HD void lane_pop(Lane& L, Stack& st) {
     /* The top three entries are read together (a frame is at most three dwords) so that the
      * reads do not wait on one another; how many are consumed is decided afterwards. */
-    uint32_t e = st.peek(L.sp - 1);
-    if (!ANYHIT) {
-        uint32_t w1 = st.peek(L.sp - 2), w2 = st.peek(L.sp - 3);
-        if (e & PT_REF_FRAME) {
-            const float inf = pt_inf();
-            float t_far = u2f(w1);
-            bool kept = (L.frame_bits & 1u) != 0;
-            float saved = kept ? u2f(w2) : inf;
-            L.sp -= kept ? 3 : 2;
-            L.frame_bits >>= 1;
-            float near_local = L.local;
-            /* near side missed (:393-394) or its closest hit lies beyond the far slab (:367) */
-            bool visit = !(near_local < inf) || (near_local > t_far);
-            L.local = saved < near_local ? saved : near_local;
-            lane_enter(L, visit ? (e & ~PT_REF_FRAME) : PT_REF_NONE);
-            return;
-        }
+    uint32_t e, w1, w2;
+    if (ANYHIT) {
+        e = st.peek1(L.sp);
+        L.sp -= 1;
+        lane_enter(L, e);
+        return;
     }
-    L.sp -= 1;
-    lane_enter(L, e);
+    st.peek3(L.sp, e, w1, w2);
+    const float inf = pt_inf();
+    const bool frame = (e & PT_REF_FRAME) != 0;
+    const bool kept = frame && (L.frame_bits & 1u) != 0;
+    const float t_far = u2f(w1);
+    const float saved = kept ? u2f(w2) : inf;
+    const float near_local = L.local;
+    /* near side missed (:393-394) or its closest hit lies beyond the far slab (:367) */
+    const bool visit = !(near_local < inf) || (near_local > t_far);
+    const float merged = saved < near_local ? saved : near_local;
+    L.sp -= frame ? (kept ? 3 : 2) : 1;
+    L.frame_bits = frame ? (L.frame_bits >> 1) : L.frame_bits;
+    L.local = frame ? merged : near_local;
+    lane_enter(L, (frame && !visit) ? PT_REF_NONE : (e & ~PT_REF_FRAME));
 }
 
 /* TAME selects the cheaper box test; it may be used only for lanes with L.tame set. */
 template <bool ANYHIT, bool TAME, class Stack>
 PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
-    StepOut o = interior_step<TAME>(n, L.r);
-    if (o.deferred != PT_REF_NONE) st.push(L.sp, o.deferred);
-    if (o.far != PT_REF_NONE) {
-        if (ANYHIT) st.push(L.sp, o.far);
-        else {
+    /* Same decisions as interior_step(), arranged so that the only data-dependent branch is
+     * the one that pushes: `first` is the child entered first (the low child when the origin
+     * overlaps both, :324-342, otherwise the near child, :315-316), `second` the other one. */
+    bool hit_lo, hit_hi;
+    if (TAME) {
+        hit_lo = box_hit_tame(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], L.r);
+        hit_hi = box_hit_tame(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], L.r);
+    } else {
+        hit_lo = box_hit(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], L.r);
+        hit_hi = box_hit(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], L.r);
+    }
+    const float origin = ray_origin_axis(L.r, n.axis);
+    const float hi_min_a = pick3(n.hi_min, n.axis), lo_max_a = pick3(n.lo_max, n.axis);
+    const bool over_hi = hi_min_a < origin;  /* :310 */
+    const bool over_lo = origin <= lo_max_a; /* :311 */
+    const bool first_is_lo = !over_hi || over_lo;
+    const uint32_t first = first_is_lo ? n.lo_ref : n.hi_ref;
+    const uint32_t second = first_is_lo ? n.hi_ref : n.lo_ref;
+    const bool hit_first = first_is_lo ? hit_lo : hit_hi;
+    const bool hit_second = first_is_lo ? hit_hi : hit_lo;
+    if (hit_first && hit_second) {
+        if (ANYHIT || (over_hi && over_lo)) {
+            /* entered afterwards whatever the first child finds; any-hit stops at the first hit,
+             * so there "afterwards" already means "the first child found nothing" */
+            st.push(L.sp, second);
+        } else {
             const float inf = pt_inf();
-            bool keep = L.local < inf;
-            if (keep) st.push(L.sp, f2u(L.local));
+            const float e = first_is_lo ? hi_min_a : lo_max_a;              /* :362 */
+            const float t_far = (e - origin) / ray_dir_axis(L.r, n.axis);   /* :364, true division */
+            const bool keep = L.local < inf;
+            st.push_frame(L.sp, keep, f2u(L.local), f2u(t_far), second | PT_REF_FRAME);
             L.frame_bits = (L.frame_bits << 1) | (keep ? 1u : 0u);
-            st.push(L.sp, f2u(o.t_far)); st.push(L.sp, o.far | PT_REF_FRAME);
             L.local = inf;
         }
     }
-    lane_enter(L, o.next);
+    lane_enter(L, hit_first ? first : (hit_second ? second : PT_REF_NONE));
 }
 
 /* One triangle of the pending leaf, in stored order, strict '<' (:281-293). */

@@ -3,7 +3,7 @@
 # Usage: bash scripts/build_variants.sh name1="-DFOO=1 -DBAR=2" name2="..."
 set -e
 cd "$(dirname "$0")/.."
-FLAGS="-std=c++17 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fPIC --offload-arch=gfx950 -Iinclude -Ipath_tracing_amd/csrc -Wno-unused-function"
+FLAGS="-std=c++17 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -fPIC --offload-arch=gfx950 -Iinclude -Ipath_tracing_amd/csrc -Wno-unused-function"
 for spec in "$@"; do
   name="${spec%%=*}"; defs="${spec#*=}"
   mkdir -p variants/$name

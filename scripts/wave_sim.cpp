@@ -1,0 +1,144 @@
+/*
+ * wave_sim.cpp -- offline model of how one 64-lane wave schedules the lane state machine.
+ *
+ * STUDY TOOL (CPU).  Drives path_tracing_amd/csrc/traverse_core.h for 64 lanes with the same
+ * refill rule as the trace kernel and charges every round an instruction cost per executed
+ * section, so that scheduling policies can be compared before touching the kernel:
+ *   policy 0  every round runs the triangle section, up to max_pops pop sections and the node
+ *             section (each only if some lane needs it)
+ *   policy 1  a round runs EITHER the triangle section (when at least tri_threshold lanes wait
+ *             on a leaf, or no lane wants a node) OR the pop+node sections
+ * Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Ipath_tracing_amd/csrc -shared -fPIC
+ */
+#include <cstdint>
+#include <cstring>
+
+#include "pt_hip.h"
+#include "traverse_core.h"
+
+namespace {
+struct CpuMem {
+    const pt_flat_node* nodes;
+    const pt_tri_isect* tris;
+    void load_node(uint32_t i, ptc::NodeData& n) const {
+        const pt_flat_node& s = nodes[i];
+        for (int k = 0; k < 3; k++) { n.lo_min[k] = s.lo_min[k]; n.lo_max[k] = s.lo_max[k]; n.hi_min[k] = s.hi_min[k]; n.hi_max[k] = s.hi_max[k]; }
+        n.lo_ref = s.lo_ref; n.hi_ref = s.hi_ref; n.axis = s.axis;
+    }
+    void load_tri(uint32_t k, ptc::TriData& t) const {
+        const pt_tri_isect& s = tris[k];
+        t.p0x = s.p0[0]; t.p0y = s.p0[1]; t.p0z = s.p0[2];
+        t.e1x = s.e1[0]; t.e1y = s.e1[1]; t.e1z = s.e1[2];
+        t.e2x = s.e2[0]; t.e2y = s.e2[1]; t.e2z = s.e2[2];
+        t.mesh_index = s.mesh_index; t.leaf_count = s.leaf_count;
+    }
+};
+struct CpuStack {
+    uint32_t data[3 * PT_MAX_TREE_DEPTH + 4];
+    void push(int& sp, uint32_t v) { data[sp++] = v; }
+    uint32_t peek(int i) const { return i >= 0 ? data[i] : 0u; }
+    uint32_t peek1(int sp) const { return peek(sp - 1); }
+    void peek3(int sp, uint32_t& e, uint32_t& w1, uint32_t& w2) const { e = peek(sp - 1); w1 = peek(sp - 2); w2 = peek(sp - 3); }
+    void push_frame(int& sp, bool keep, uint32_t a, uint32_t b, uint32_t c) { if (keep) push(sp, a); push(sp, b); push(sp, c); }
+};
+}
+
+extern "C" {
+
+struct SimParams {
+    int policy, refill_min, tri_threshold, max_pops, tris_per_round, any_hit;
+    double c_round, c_tri, c_pop, c_node, c_start;
+};
+struct SimStats {
+    double cost;
+    uint64_t rounds, tri_sections, pop_sections, node_sections, start_sections;
+    uint64_t lane_tri, lane_pop, lane_node, lane_pop_culled;
+};
+
+void wave_sim(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const SimParams* p, SimStats* out) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    ptc::RootBox root;
+    root.mnx = sc->root_min[0]; root.mny = sc->root_min[1]; root.mnz = sc->root_min[2];
+    root.mxx = sc->root_max[0]; root.mxy = sc->root_max[1]; root.mxz = sc->root_max[2];
+    const bool scene_tame = ptc::root_is_tame(root);
+    static ptc::Lane L[64];
+    static CpuStack st[64];
+    bool active[64];
+    for (int i = 0; i < 64; i++) active[i] = false;
+    uint64_t next = 0;
+    SimStats s;
+    memset(&s, 0, sizeof s);
+    const bool any = p->any_hit != 0;
+    while (true) {
+        int idle = 0;
+        for (int i = 0; i < 64; i++) idle += !active[i];
+        bool starting = false;
+        int start_list[64], n_start = 0;
+        if (idle && next < n && (idle >= p->refill_min || idle == 64)) {
+            for (int i = 0; i < 64 && next < n; i++) if (!active[i]) start_list[n_start++] = i, next++;
+            starting = n_start > 0;
+        }
+        if (next >= n && idle == 64 && !starting) break;
+        s.rounds++;
+        s.cost += p->c_round;
+        int nt = 0, nn = 0;
+        for (int i = 0; i < 64; i++) if (active[i]) { if (ptc::lane_has_leaf(L[i])) nt++; else nn++; }
+        bool run_tri = nt > 0, run_node = nn > 0;
+        if (p->policy == 1 && nt > 0 && nn > 0) {
+            if (nt >= p->tri_threshold) run_node = false; else run_tri = false;
+        }
+        bool did_tri[64];
+        for (int i = 0; i < 64; i++) did_tri[i] = false;
+        if (run_tri) {
+            for (int k = 0; k < p->tris_per_round; k++) {
+                bool some = false;
+                for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_has_leaf(L[i]) && (k == 0 || L[i].leaf_end != PT_LEAF_UNKNOWN)) {
+                    ptc::TriData tr; mem.load_tri(L[i].leaf_pos, tr);
+                    if (any) ptc::lane_tri<true>(L[i], tr); else ptc::lane_tri<false>(L[i], tr);
+                    s.lane_tri++; some = true; did_tri[i] = true;
+                }
+                if (some) { s.tri_sections++; s.cost += p->c_tri; }
+            }
+        }
+        if (run_node) {
+            for (int k = 0; k < p->max_pops; k++) {
+                bool some = false;
+                for (int i = 0; i < 64; i++) {
+                    ptc::Lane& l = L[i];
+                    /* a lane that did a triangle this round does not also pop */
+                    if (!active[i] || did_tri[i] || ptc::lane_has_leaf(l) || ptc::lane_has_node(l) || l.sp <= 0) continue;
+                    if (any) ptc::lane_pop<true>(l, st[i]); else ptc::lane_pop<false>(l, st[i]);
+                    s.lane_pop++; some = true;
+                    if (!ptc::lane_has_leaf(l) && !ptc::lane_has_node(l)) s.lane_pop_culled++;
+                }
+                if (some) { s.pop_sections++; s.cost += p->c_pop; }
+            }
+            bool some = false;
+            for (int i = 0; i < 64; i++) {
+                ptc::Lane& l = L[i];
+                if (!active[i] || did_tri[i] || ptc::lane_has_leaf(l) || !ptc::lane_has_node(l)) continue;
+                ptc::NodeData nd; mem.load_node(l.cur, nd);
+                if (any) { if (l.tame) ptc::lane_node<true, true>(l, nd, st[i]); else ptc::lane_node<true, false>(l, nd, st[i]); }
+                else { if (l.tame) ptc::lane_node<false, true>(l, nd, st[i]); else ptc::lane_node<false, false>(l, nd, st[i]); }
+                s.lane_node++; some = true;
+            }
+            if (some) { s.node_sections++; s.cost += p->c_node; }
+        }
+        for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_finished(L[i])) active[i] = false;
+        if (starting) {
+            s.start_sections++; s.cost += p->c_start;
+            for (int k = 0; k < n_start; k++) {
+                int i = start_list[k];
+                uint64_t r = next - n_start + k;
+                L[i].r.ox = o[3 * r]; L[i].r.oy = o[3 * r + 1]; L[i].r.oz = o[3 * r + 2];
+                L[i].r.dx = d[3 * r]; L[i].r.dy = d[3 * r + 1]; L[i].r.dz = d[3 * r + 2];
+                ptc::ray_set_recip(L[i].r);
+                ptc::lane_start(L[i], sc->root_ref, root, scene_tame);
+                active[i] = !ptc::lane_finished(L[i]);
+            }
+        }
+    }
+    *out = s;
+}
+
+}

@@ -41,6 +41,9 @@ struct CpuStack {
         if (sp > max_sp) max_sp = sp;
     }
     uint32_t peek(int i) const { return i >= 0 ? data[i] : 0u; }
+    uint32_t peek1(int sp) const { return peek(sp - 1); }
+    void peek3(int sp, uint32_t& e, uint32_t& w1, uint32_t& w2) const { e = peek(sp - 1); w1 = peek(sp - 2); w2 = peek(sp - 3); }
+    void push_frame(int& sp, bool keep, uint32_t a, uint32_t b, uint32_t c) { if (keep) push(sp, a); push(sp, b); push(sp, c); }
 };
 
 ptc::RootBox root_of(const pt_flat_scene* sc) {
