@@ -56,7 +56,7 @@ typedef struct pt_tri_isect {
     float    p0[3], e1[3], e2[3];    /* points[0], edge01, edge02 */
     uint32_t mesh_index;             /* index of this triangle in the input mesh */
     uint32_t leaf_count;             /* triangles in this leaf; valid in a leaf's first record */
-    uint32_t pad;
+    uint32_t leaf_remaining;         /* triangles that follow this one in its leaf (0 = last)  */
 } pt_tri_isect;                      /* 48 bytes */
 
 /* Shading record, same order: what Integrator::cast_ray reads after a hit

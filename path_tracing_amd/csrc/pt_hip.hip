@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     st.spill = a.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
 
     Lane L;
-    L.cur = PT_REF_NONE; L.leaf_pos = L.leaf_end = 0; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
+    L.cur = PT_REF_NONE; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
     int32_t ray = -1;         /* index of the ray this lane is tracing, or -1 (idle) */
     float dist = 0.0f;
     uint32_t pool_next = 0, pool_end = 0; /* wave-uniform: unclaimed rays of the current chunk */
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         const bool do_node = active && !do_tri && lane_has_node(L);
         float4 q0, q1, q2, q3;   /* meaningful only in lanes with do_tri / do_node */
         if (do_tri || do_node) {
-            const float4* rec = do_tri ? sc.tris + (size_t)L.leaf_pos * 3 : sc.nodes + (size_t)L.cur * 4;
+            const float4* rec = do_tri ? sc.tris + (size_t)lane_leaf_pos(L) * 3 : sc.nodes + (size_t)L.cur * 4;
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             if (do_node) q3 = rec[3];
         }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             tr.p0x = q0.x; tr.p0y = q0.y; tr.p0z = q0.z;
             tr.e1x = q0.w; tr.e1y = q1.x; tr.e1z = q1.y;
             tr.e2x = q1.z; tr.e2y = q1.w; tr.e2z = q2.x;
-            tr.mesh_index = __float_as_uint(q2.y); tr.leaf_count = __float_as_uint(q2.z);
+            tr.mesh_index = __float_as_uint(q2.y); tr.leaf_remaining = __float_as_uint(q2.w);
             lane_tri<ANY>(L, tr);
         }
         {
@@ -294,9 +294,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             }
         }
         /* ---- lanes left with neither a leaf nor a node take their next one from the stack ---- */
-        if (active && !lane_has_leaf(L) && !lane_has_node(L) && L.sp > 0) {
+        if (active && L.cur == PT_REF_NONE && L.sp > 0) {
             lane_pop<ANY>(L, st);
-            if (!lane_has_node(L) && !lane_has_leaf(L) && L.sp > 0) lane_pop<ANY>(L, st);
+            if (L.cur == PT_REF_NONE && L.sp > 0) lane_pop<ANY>(L, st);
         }
         /* ---- retire finished rays ---- */
         if (active && lane_finished(L)) {
@@ -663,6 +663,9 @@ static int validate_flat(const pt_flat_scene* f) {
             if (start >= f->n_tris) return fail(PT_ERR_INVALID, "leaf start outside the triangle array");
             if (count == 0) count = f->tris[start].leaf_count;
             if (count == 0 || (uint64_t)start + count > f->n_tris) return fail(PT_ERR_INVALID, "leaf range outside the triangle array");
+            /* the kernels walk a leaf by its records' leaf_remaining fields */
+            for (uint32_t k = 0; k < count; k++)
+                if (f->tris[start + k].leaf_remaining != count - 1 - k) return fail(PT_ERR_INVALID, "leaf_remaining does not count down to the leaf's end");
             tri_total += count;
             continue;
         }

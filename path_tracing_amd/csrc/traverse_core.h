@@ -87,9 +87,10 @@ PT_HD bool box_hit_tame(float mnx, float mny, float mnz, float mxx, float mxy, f
     float t1x = (mxx - r.ox) * r.rx, t1y = (mxy - r.oy) * r.ry, t1z = (mxz - r.oz) * r.rz;
     float enx = __builtin_fminf(t0x, t1x), eny = __builtin_fminf(t0y, t1y), enz = __builtin_fminf(t0z, t1z);
     float exx = __builtin_fmaxf(t0x, t1x), exy = __builtin_fmaxf(t0y, t1y), exz = __builtin_fmaxf(t0z, t1z);
-    float t_start = __builtin_fmaxf(enx, __builtin_fmaxf(eny, enz));
+    /* !(t_end < 0) && !(t_start > t_end), folded: without NaNs that is max(t_start, 0) <= t_end */
+    float t_start0 = __builtin_fmaxf(__builtin_fmaxf(enx, eny), __builtin_fmaxf(enz, 0.0f));
     float t_end = __builtin_fminf(exx, __builtin_fminf(exy, exz));
-    return !(t_end < 0.0f) && !(t_start > t_end);
+    return t_start0 <= t_end;
 }
 
 /* A ray is tame when no box test on it can produce a NaN: finite, non-zero reciprocals
@@ -112,7 +113,8 @@ struct TriData {
     float p0x, p0y, p0z;
     float e1x, e1y, e1z;
     float e2x, e2y, e2z;
-    uint32_t mesh_index, leaf_count;
+    uint32_t mesh_index;
+    uint32_t leaf_remaining; /* triangles that follow this one in its leaf (0 = last) */
 };
 
 PT_HD bool tri_hit(const TriData& tr, const Ray9& r, float& t_out, float& u_out, float& v_out) {
@@ -238,11 +240,14 @@ PT_HD uint32_t ref_leaf_count(uint32_t ref) { return (ref >> PT_REF_COUNT_SHIFT)
  * visited iff the near side found nothing, which needs no frame (a plain deferred reference
  * does it), so 1 * PT_MAX_TREE_DEPTH dwords suffice.
  *
- * A lane is always in exactly one of these situations:
- *   leaf pending   (leaf_pos != leaf_end)  -> lane_tri() with the triangle at leaf_pos
- *   interior node  (cur != NONE)           -> lane_node() with that node
- *   neither, stack not empty               -> lane_pop()
- *   neither, stack empty                   -> finished
+ * A lane's position is one word, `cur`: PT_REF_NONE, an interior node index, or a leaf
+ * reference whose start field walks through the leaf's triangles (each triangle record says
+ * how many follow it, so the count field of the reference is not needed).  A lane is always in
+ * exactly one of these situations:
+ *   leaf pending   (cur is a leaf reference)  -> lane_tri() with the triangle lane_leaf_pos()
+ *   interior node  (cur is a node index)      -> lane_node() with that node
+ *   neither, stack not empty                  -> lane_pop()
+ *   neither, stack empty                      -> finished
  * Stack is private to the lane and supplies
  *   push(int& sp, v)                         store v at entry sp, advance sp
  *   push_frame(int& sp, keep, a, b, c)       push a (only if keep), then b, then c
@@ -253,38 +258,26 @@ struct Lane {
     Ray9 r;
     Hit best;
     float local;
-    uint32_t cur;                /* interior node to visit, or PT_REF_NONE */
-    uint32_t leaf_pos, leaf_end; /* pending leaf triangles; leaf_end == PT_LEAF_UNKNOWN until the
-                                    first record of an oversized leaf has been read */
+    uint32_t cur;
     uint32_t frame_bits;
     int sp;
     bool found;
     bool tame;                   /* ray_is_tame(r) and the scene's boxes are of moderate size */
 };
-#define PT_LEAF_UNKNOWN 0xffffffffu
 
-PT_HD bool lane_has_leaf(const Lane& L) { return L.leaf_pos != L.leaf_end; }
-PT_HD bool lane_has_node(const Lane& L) { return L.cur != PT_REF_NONE; }
-PT_HD bool lane_finished(const Lane& L) { return !lane_has_leaf(L) && !lane_has_node(L) && L.sp == 0; }
+/* PT_REF_NONE is -1 as a signed word, leaf references are the other negative words. */
+PT_HD bool lane_has_leaf(const Lane& L) { return (int32_t)L.cur < -1; }
+PT_HD bool lane_has_node(const Lane& L) { return (int32_t)L.cur >= 0; }
+PT_HD uint32_t lane_leaf_pos(const Lane& L) { return L.cur & PT_REF_START_MASK; }
+PT_HD bool lane_finished(const Lane& L) { return L.cur == PT_REF_NONE && L.sp == 0; }
 
-/* Routes a child reference: interior nodes go to `cur`, leaves become the pending leaf. */
-PT_HD void lane_enter(Lane& L, uint32_t ref) {
-    if (ref != PT_REF_NONE && ref_is_leaf(ref)) {
-        uint32_t start = ref_leaf_start(ref), count = ref_leaf_count(ref);
-        L.leaf_pos = start;
-        L.leaf_end = count ? start + count : PT_LEAF_UNKNOWN;
-        L.cur = PT_REF_NONE;
-    } else {
-        L.cur = ref;
-    }
-}
+PT_HD void lane_enter(Lane& L, uint32_t ref) { L.cur = ref; }
 
 PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root, bool scene_tame) {
     const float inf = pt_inf();
     L.tame = scene_tame && ray_is_tame(L.r);
     L.best.t = inf; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0xffffffffu; L.best.mesh = 0xffffffffu;
     L.local = inf;
-    L.leaf_pos = 0; L.leaf_end = 0;
     L.frame_bits = 0; L.sp = 0; L.found = false;
     lane_enter(L, box_hit(root.mnx, root.mny, root.mnz, root.mxx, root.mxy, root.mxz, L.r) ? root_ref : PT_REF_NONE);
 }
@@ -337,8 +330,9 @@ PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
     const bool first_is_lo = !over_hi || over_lo;
     const uint32_t first = first_is_lo ? n.lo_ref : n.hi_ref;
     const uint32_t second = first_is_lo ? n.hi_ref : n.lo_ref;
-    const bool hit_first = first_is_lo ? hit_lo : hit_hi;
-    const bool hit_second = first_is_lo ? hit_hi : hit_lo;
+    /* and/or on the two outcomes instead of selects, so they stay wave masks */
+    const bool hit_first = (first_is_lo && hit_lo) || (!first_is_lo && hit_hi);
+    const bool hit_second = (first_is_lo && hit_hi) || (!first_is_lo && hit_lo);
     if (hit_first && hit_second) {
         if (ANYHIT || (over_hi && over_lo)) {
             /* entered afterwards whatever the first child finds; any-hit stops at the first hit,
@@ -360,14 +354,13 @@ PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
 /* One triangle of the pending leaf, in stored order, strict '<' (:281-293). */
 template <bool ANYHIT>
 PT_HD void lane_tri(Lane& L, const TriData& tr) {
-    if (L.leaf_end == PT_LEAF_UNKNOWN) L.leaf_end = L.leaf_pos + tr.leaf_count;
     float t, u, v;
     if (tri_hit(tr, L.r, t, u, v)) {
-        if (t < L.best.t) { L.best.t = t; L.best.u = u; L.best.v = v; L.best.tri = L.leaf_pos; L.best.mesh = tr.mesh_index; L.found = true; }
+        if (t < L.best.t) { L.best.t = t; L.best.u = u; L.best.v = v; L.best.tri = lane_leaf_pos(L); L.best.mesh = tr.mesh_index; L.found = true; }
         if (t < L.local) L.local = t;
     }
-    L.leaf_pos++;
-    if (ANYHIT && L.found) { L.leaf_pos = L.leaf_end = 0; L.cur = PT_REF_NONE; L.sp = 0; } /* nothing left to do */
+    L.cur = tr.leaf_remaining ? L.cur + 1u : PT_REF_NONE;
+    if (ANYHIT && L.found) { L.cur = PT_REF_NONE; L.sp = 0; } /* nothing left to do */
 }
 
 /* Runs one lane to completion (the CPU emulation's driver; the kernels interleave the same
@@ -379,7 +372,7 @@ PT_HD bool trace_lane(const Mem& mem, uint32_t root_ref, const RootBox& root, co
     L.r = r;
     lane_start(L, root_ref, root, root_is_tame(root));
     while (!lane_finished(L)) {
-        if (lane_has_leaf(L)) { TriData tr; mem.load_tri(L.leaf_pos, tr); lane_tri<ANYHIT>(L, tr); }
+        if (lane_has_leaf(L)) { TriData tr; mem.load_tri(lane_leaf_pos(L), tr); lane_tri<ANYHIT>(L, tr); }
         else if (lane_has_node(L)) {
             NodeData n;
             mem.load_node(L.cur, n);

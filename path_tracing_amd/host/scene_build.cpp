@@ -319,7 +319,11 @@ uint32_t flatten_rec(const BNode* n, Flat& f, uint32_t& max_depth) {
 }
 
 void mark_leaf_counts(const BNode* n, Flat& f) {
-    if (n->leaf) { if (n->count > 0) f.tris[(size_t)n->begin].leaf_count = (uint32_t)n->count; return; }
+    if (n->leaf) {
+        if (n->count > 0) f.tris[(size_t)n->begin].leaf_count = (uint32_t)n->count;
+        for (int64_t k = 0; k < n->count; k++) f.tris[(size_t)(n->begin + k)].leaf_remaining = (uint32_t)(n->count - 1 - k);
+        return;
+    }
     mark_leaf_counts(n->lo, f);
     mark_leaf_counts(n->hi, f);
 }
@@ -343,7 +347,7 @@ void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm,
         ti.p0[0] = m.p0[i].x; ti.p0[1] = m.p0[i].y; ti.p0[2] = m.p0[i].z;
         ti.e1[0] = e1.x; ti.e1[1] = e1.y; ti.e1[2] = e1.z;
         ti.e2[0] = e2.x; ti.e2[1] = e2.y; ti.e2[2] = e2.z;
-        ti.mesh_index = (uint32_t)i; ti.leaf_count = 0; ti.pad = 0;
+        ti.mesh_index = (uint32_t)i; ti.leaf_count = 0; ti.leaf_remaining = 0;
         pt_tri_shade& ts = f.shade[(size_t)k];
         memset(&ts, 0, sizeof(ts));
         ts.normal[0] = m.normal[i].x; ts.normal[1] = m.normal[i].y; ts.normal[2] = m.normal[i].z;

@@ -34,7 +34,7 @@ NODE_DTYPE = np.dtype([("lo_min", "<f4", (3,)), ("lo_max", "<f4", (3,)), ("hi_mi
                        ("hi_max", "<f4", (3,)), ("lo_ref", "<u4"), ("hi_ref", "<u4"), ("axis", "<u4"),
                        ("pad", "<u4")])
 ISECT_DTYPE = np.dtype([("p0", "<f4", (3,)), ("e1", "<f4", (3,)), ("e2", "<f4", (3,)), ("mesh_index", "<u4"),
-                        ("leaf_count", "<u4"), ("pad", "<u4")])
+                        ("leaf_count", "<u4"), ("leaf_remaining", "<u4")])
 SHADE_DTYPE = np.dtype([("normal", "<f4", (3,)), ("plane", "<f4"), ("base_n", "<f4", (3,)), ("pad0", "<f4"),
                         ("u_n", "<f4", (3,)), ("pad1", "<f4"), ("v_n", "<f4", (3,)), ("pad2", "<f4")])
 assert NODE_DTYPE.itemsize == 64 and ISECT_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 64

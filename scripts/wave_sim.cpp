@@ -30,7 +30,7 @@ struct CpuMem {
         t.p0x = s.p0[0]; t.p0y = s.p0[1]; t.p0z = s.p0[2];
         t.e1x = s.e1[0]; t.e1y = s.e1[1]; t.e1z = s.e1[2];
         t.e2x = s.e2[0]; t.e2y = s.e2[1]; t.e2z = s.e2[2];
-        t.mesh_index = s.mesh_index; t.leaf_count = s.leaf_count;
+        t.mesh_index = s.mesh_index; t.leaf_remaining = s.leaf_remaining;
     }
 };
 struct CpuStack {
@@ -92,8 +92,8 @@ void wave_sim(const pt_flat_scene* sc, uint64_t n, const float* o, const float* 
         if (run_tri) {
             for (int k = 0; k < p->tris_per_round; k++) {
                 bool some = false;
-                for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_has_leaf(L[i]) && (k == 0 || L[i].leaf_end != PT_LEAF_UNKNOWN)) {
-                    ptc::TriData tr; mem.load_tri(L[i].leaf_pos, tr);
+                for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_has_leaf(L[i])) {
+                    ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L[i]), tr);
                     if (any) ptc::lane_tri<true>(L[i], tr); else ptc::lane_tri<false>(L[i], tr);
                     s.lane_tri++; some = true; did_tri[i] = true;
                 }
@@ -106,7 +106,7 @@ void wave_sim(const pt_flat_scene* sc, uint64_t n, const float* o, const float* 
                 for (int i = 0; i < 64; i++) {
                     ptc::Lane& l = L[i];
                     /* a lane that did a triangle this round does not also pop */
-                    if (!active[i] || did_tri[i] || ptc::lane_has_leaf(l) || ptc::lane_has_node(l) || l.sp <= 0) continue;
+                    if (!active[i] || l.cur != PT_REF_NONE || l.sp <= 0) continue;
                     if (any) ptc::lane_pop<true>(l, st[i]); else ptc::lane_pop<false>(l, st[i]);
                     s.lane_pop++; some = true;
                     if (!ptc::lane_has_leaf(l) && !ptc::lane_has_node(l)) s.lane_pop_culled++;
@@ -116,7 +116,7 @@ void wave_sim(const pt_flat_scene* sc, uint64_t n, const float* o, const float* 
             bool some = false;
             for (int i = 0; i < 64; i++) {
                 ptc::Lane& l = L[i];
-                if (!active[i] || did_tri[i] || ptc::lane_has_leaf(l) || !ptc::lane_has_node(l)) continue;
+                if (!active[i] || did_tri[i] || !ptc::lane_has_node(l)) continue;
                 ptc::NodeData nd; mem.load_node(l.cur, nd);
                 if (any) { if (l.tame) ptc::lane_node<true, true>(l, nd, st[i]); else ptc::lane_node<true, false>(l, nd, st[i]); }
                 else { if (l.tame) ptc::lane_node<false, true>(l, nd, st[i]); else ptc::lane_node<false, false>(l, nd, st[i]); }

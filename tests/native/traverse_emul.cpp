@@ -27,7 +27,7 @@ struct CpuMem {
         t.p0x = s.p0[0]; t.p0y = s.p0[1]; t.p0z = s.p0[2];
         t.e1x = s.e1[0]; t.e1y = s.e1[1]; t.e1z = s.e1[2];
         t.e2x = s.e2[0]; t.e2y = s.e2[1]; t.e2z = s.e2[2];
-        t.mesh_index = s.mesh_index; t.leaf_count = s.leaf_count;
+        t.mesh_index = s.mesh_index; t.leaf_remaining = s.leaf_remaining;
     }
 };
 
@@ -122,7 +122,7 @@ extern "C" int emul_step_trace(const pt_flat_scene* sc, const float* o, const fl
     ptc::lane_start(L, sc->root_ref, root_of(sc), true);
     while (!ptc::lane_finished(L)) {
         if (n >= cap) return -1;
-        if (ptc::lane_has_leaf(L)) { ptc::TriData tr; mem.load_tri(L.leaf_pos, tr); ptc::lane_tri<false>(L, tr); out[n++] = 'T'; }
+        if (ptc::lane_has_leaf(L)) { ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L), tr); ptc::lane_tri<false>(L, tr); out[n++] = 'T'; }
         else if (ptc::lane_has_node(L)) {
             ptc::NodeData nd; mem.load_node(L.cur, nd);
             if (L.tame) ptc::lane_node<false, true>(L, nd, st); else ptc::lane_node<false, false>(L, nd, st);
