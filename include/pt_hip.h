@@ -42,10 +42,11 @@ extern "C" {
 
 /* One interior node of the reference's tree (kdTreeNode, kdtree.h:19-36), holding the
  * AABBs of BOTH children so a visit needs one 64-byte load.  The node's own box lives in
- * its parent (the root's in pt_flat_scene). */
+ * its parent (the root's in pt_flat_scene).  A box is stored per axis as {minimum, maximum},
+ * the order in which the slab test consumes it. */
 typedef struct pt_flat_node {
-    float    lo_min[3], lo_max[3];   /* low_side->aabb   */
-    float    hi_min[3], hi_max[3];   /* high_side->aabb  */
+    float    lo[3][2];               /* low_side->aabb:  lo[axis] = {minima[axis], maxima[axis]} */
+    float    hi[3][2];               /* high_side->aabb: same layout */
     uint32_t lo_ref, hi_ref;
     uint32_t axis;                   /* split_axis       */
     uint32_t pad;

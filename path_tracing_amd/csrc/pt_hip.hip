@@ -282,10 +282,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         }
         {
             NodeData nd;
-            nd.lo_min[0] = q0.x; nd.lo_min[1] = q0.y; nd.lo_min[2] = q0.z;
-            nd.lo_max[0] = q0.w; nd.lo_max[1] = q1.x; nd.lo_max[2] = q1.y;
-            nd.hi_min[0] = q1.z; nd.hi_min[1] = q1.w; nd.hi_min[2] = q2.x;
-            nd.hi_max[0] = q2.y; nd.hi_max[1] = q2.z; nd.hi_max[2] = q2.w;
+            nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
+            nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
             nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
             if (__any(do_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
                 if (do_node) lane_node<ANY, false>(L, nd, st);

@@ -64,11 +64,25 @@ PT_HD float sel3(uint32_t k, float a, float b, float c) {
 PT_HD float ray_origin_axis(const Ray9& r, uint32_t a) { return sel3(a, r.ox, r.oy, r.oz); }
 PT_HD float ray_dir_axis(const Ray9& r, uint32_t a) { return sel3(a, r.dx, r.dy, r.dz); }
 
-PT_HD bool box_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const Ray9& r) {
-    float t0x = (mnx - r.ox) * r.rx, t0y = (mny - r.oy) * r.ry, t0z = (mnz - r.oz) * r.rz;
-    float t1x = (mxx - r.ox) * r.rx, t1y = (mxy - r.oy) * r.ry, t1z = (mxz - r.oz) * r.rz;
-    float enx = sel_min(t0x, t1x), eny = sel_min(t0y, t1y), enz = sel_min(t0z, t1z);
-    float exx = sel_max(t0x, t1x), exy = sel_max(t0y, t1y), exz = sel_max(t0z, t1z);
+/* A pair of floats: {minimum, maximum} of a box along one axis. */
+typedef float pt_f2 __attribute__((vector_size(8)));
+
+/* A box as three {minimum, maximum} pairs. */
+struct Box2 { pt_f2 x, y, z; };
+
+/* (bounds - origin) * reciprocal for both bounds of each axis (utils.cpp:64-69). */
+PT_HD void slab_params(const Box2& b, const Ray9& r, pt_f2& tx, pt_f2& ty, pt_f2& tz) {
+    /* written per element: packed-f32 arithmetic on these pairs was measured no faster on gfx950 */
+    tx = pt_f2{(b.x[0] - r.ox) * r.rx, (b.x[1] - r.ox) * r.rx};
+    ty = pt_f2{(b.y[0] - r.oy) * r.ry, (b.y[1] - r.oy) * r.ry};
+    tz = pt_f2{(b.z[0] - r.oz) * r.rz, (b.z[1] - r.oz) * r.rz};
+}
+
+PT_HD bool box_hit(const Box2& b, const Ray9& r) {
+    pt_f2 tx, ty, tz;
+    slab_params(b, r, tx, ty, tz);
+    float enx = sel_min(tx[0], tx[1]), eny = sel_min(ty[0], ty[1]), enz = sel_min(tz[0], tz[1]);
+    float exx = sel_max(tx[0], tx[1]), exy = sel_max(ty[0], ty[1]), exz = sel_max(tz[0], tz[1]);
     float t_start = sel_max(enx, sel_max(eny, enz));
     float t_end = sel_min(exx, sel_min(exy, exz));
     if (t_end < 0.0f) return false;
@@ -82,11 +96,11 @@ PT_HD bool box_hit(float mnx, float mny, float mnz, float mxx, float mxy, float 
  * non-zero and origin and box coordinates are finite and of moderate size (lane_is_tame);
  * the sign of zero never changes the two comparisons below.  So for tame rays both forms give
  * the same answer, and this one is about a third cheaper. */
-PT_HD bool box_hit_tame(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const Ray9& r) {
-    float t0x = (mnx - r.ox) * r.rx, t0y = (mny - r.oy) * r.ry, t0z = (mnz - r.oz) * r.rz;
-    float t1x = (mxx - r.ox) * r.rx, t1y = (mxy - r.oy) * r.ry, t1z = (mxz - r.oz) * r.rz;
-    float enx = __builtin_fminf(t0x, t1x), eny = __builtin_fminf(t0y, t1y), enz = __builtin_fminf(t0z, t1z);
-    float exx = __builtin_fmaxf(t0x, t1x), exy = __builtin_fmaxf(t0y, t1y), exz = __builtin_fmaxf(t0z, t1z);
+PT_HD bool box_hit_tame(const Box2& b, const Ray9& r) {
+    pt_f2 tx, ty, tz;
+    slab_params(b, r, tx, ty, tz);
+    float enx = __builtin_fminf(tx[0], tx[1]), eny = __builtin_fminf(ty[0], ty[1]), enz = __builtin_fminf(tz[0], tz[1]);
+    float exx = __builtin_fmaxf(tx[0], tx[1]), exy = __builtin_fmaxf(ty[0], ty[1]), exz = __builtin_fmaxf(tz[0], tz[1]);
     /* !(t_end < 0) && !(t_start > t_end), folded: without NaNs that is max(t_start, 0) <= t_end */
     float t_start0 = __builtin_fmaxf(__builtin_fmaxf(enx, eny), __builtin_fmaxf(enz, 0.0f));
     float t_end = __builtin_fminf(exx, __builtin_fminf(exy, exz));
@@ -141,62 +155,9 @@ PT_HD bool tri_hit(const TriData& tr, const Ray9& r, float& t_out, float& u_out,
 }
 
 struct NodeData {
-    float lo_min[3], lo_max[3], hi_min[3], hi_max[3];
+    pt_f2 lo[3], hi[3];          /* children's boxes, {minimum, maximum} per axis */
     uint32_t lo_ref, hi_ref, axis;
 };
-
-PT_HD float pick3(const float* a, uint32_t k) { return sel3(k, a[0], a[1], a[2]); }
-
-/* What visiting one interior node decides (kdtree.cpp:307-316, 324-394), with both children's
- * box tests (the first statement of each child's own ray_test, :273) already folded in:
- *   next        child to enter now, or PT_REF_NONE
- *   deferred    child to enter afterwards unconditionally (the "overlaps both" case), or NONE
- *   far         child whose visit depends on the near side's result, or NONE; t_far is the ray
- *               parameter of its slab along the split axis (:362-364)
- * A child whose box is missed contributes nothing, exactly as its ray_test returning false. */
-struct StepOut {
-    uint32_t next, deferred, far;
-    float t_far;
-};
-
-template <bool TAME>
-PT_HD StepOut interior_step(const NodeData& n, const Ray9& r) {
-    StepOut o;
-    o.next = PT_REF_NONE; o.deferred = PT_REF_NONE; o.far = PT_REF_NONE; o.t_far = 0.0f;
-    bool hit_lo, hit_hi;
-    if (TAME) {
-        hit_lo = box_hit_tame(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], r);
-        hit_hi = box_hit_tame(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], r);
-    } else {
-        hit_lo = box_hit(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], r);
-        hit_hi = box_hit(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], r);
-    }
-    float origin = ray_origin_axis(r, n.axis);
-    float hi_min_a = pick3(n.hi_min, n.axis), lo_max_a = pick3(n.lo_max, n.axis);
-    bool over_hi = hi_min_a < origin;  /* :310 */
-    bool over_lo = origin <= lo_max_a; /* :311 */
-    if (over_hi && over_lo) {          /* :324-342: low first, then high, both unconditionally */
-        if (hit_lo) { o.next = n.lo_ref; if (hit_hi) o.deferred = n.hi_ref; }
-        else if (hit_hi) o.next = n.hi_ref;
-        return o;
-    }
-    bool near_is_lo = !over_hi;        /* :315-316 */
-    uint32_t near_ref = near_is_lo ? n.lo_ref : n.hi_ref;
-    uint32_t far_ref = near_is_lo ? n.hi_ref : n.lo_ref;
-    bool hit_near = near_is_lo ? hit_lo : hit_hi;
-    bool hit_far = near_is_lo ? hit_hi : hit_lo;
-    if (hit_near) {
-        o.next = near_ref;
-        if (hit_far) {
-            float e = near_is_lo ? hi_min_a : lo_max_a;      /* :362 */
-            o.far = far_ref;
-            o.t_far = (e - origin) / ray_dir_axis(r, n.axis); /* :364, true division */
-        }
-    } else if (hit_far) {
-        o.next = far_ref;              /* :393-394 */
-    }
-    return o;
-}
 
 struct Hit {
     float t, u, v;
@@ -279,7 +240,9 @@ PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root, bool scen
     L.best.t = inf; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0xffffffffu; L.best.mesh = 0xffffffffu;
     L.local = inf;
     L.frame_bits = 0; L.sp = 0; L.found = false;
-    lane_enter(L, box_hit(root.mnx, root.mny, root.mnz, root.mxx, root.mxy, root.mxz, L.r) ? root_ref : PT_REF_NONE);
+    Box2 rb;
+    rb.x = pt_f2{root.mnx, root.mxx}; rb.y = pt_f2{root.mny, root.mxy}; rb.z = pt_f2{root.mnz, root.mxz};
+    lane_enter(L, box_hit(rb, L.r) ? root_ref : PT_REF_NONE);
 }
 
 template <bool ANYHIT, class Stack>
@@ -312,19 +275,20 @@ PT_HD void lane_pop(Lane& L, Stack& st) {
 /* TAME selects the cheaper box test; it may be used only for lanes with L.tame set. */
 template <bool ANYHIT, bool TAME, class Stack>
 PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
-    /* Same decisions as interior_step(), arranged so that the only data-dependent branch is
-     * the one that pushes: `first` is the child entered first (the low child when the origin
+    /* What visiting one interior node decides (kdtree.cpp:307-316, 324-394), with both
+     * children's box tests (the first statement of each child's own ray_test, :273) folded in;
+     * a child whose box is missed contributes nothing, exactly as its ray_test returning false.
+     * Arranged so that the only data-dependent branch is the one that pushes: `first` is the
+     * child entered first (the low child when the origin
      * overlaps both, :324-342, otherwise the near child, :315-316), `second` the other one. */
-    bool hit_lo, hit_hi;
-    if (TAME) {
-        hit_lo = box_hit_tame(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], L.r);
-        hit_hi = box_hit_tame(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], L.r);
-    } else {
-        hit_lo = box_hit(n.lo_min[0], n.lo_min[1], n.lo_min[2], n.lo_max[0], n.lo_max[1], n.lo_max[2], L.r);
-        hit_hi = box_hit(n.hi_min[0], n.hi_min[1], n.hi_min[2], n.hi_max[0], n.hi_max[1], n.hi_max[2], L.r);
-    }
+    Box2 lo, hi;
+    lo.x = n.lo[0]; lo.y = n.lo[1]; lo.z = n.lo[2];
+    hi.x = n.hi[0]; hi.y = n.hi[1]; hi.z = n.hi[2];
+    const bool hit_lo = TAME ? box_hit_tame(lo, L.r) : box_hit(lo, L.r);
+    const bool hit_hi = TAME ? box_hit_tame(hi, L.r) : box_hit(hi, L.r);
     const float origin = ray_origin_axis(L.r, n.axis);
-    const float hi_min_a = pick3(n.hi_min, n.axis), lo_max_a = pick3(n.lo_max, n.axis);
+    const float hi_min_a = sel3(n.axis, n.hi[0][0], n.hi[1][0], n.hi[2][0]);
+    const float lo_max_a = sel3(n.axis, n.lo[0][1], n.lo[1][1], n.lo[2][1]);
     const bool over_hi = hi_min_a < origin;  /* :310 */
     const bool over_lo = origin <= lo_max_a; /* :311 */
     const bool first_is_lo = !over_hi || over_lo;

@@ -311,8 +311,8 @@ uint32_t flatten_rec(const BNode* n, Flat& f, uint32_t& max_depth) {
     uint32_t hi = flatten_rec(n->hi, f, max_depth);
     pt_flat_node& fn = f.nodes[me];
     for (int a = 0; a < 3; a++) {
-        fn.lo_min[a] = n->lo->bmin[a]; fn.lo_max[a] = n->lo->bmax[a];
-        fn.hi_min[a] = n->hi->bmin[a]; fn.hi_max[a] = n->hi->bmax[a];
+        fn.lo[a][0] = n->lo->bmin[a]; fn.lo[a][1] = n->lo->bmax[a];
+        fn.hi[a][0] = n->hi->bmin[a]; fn.hi[a][1] = n->hi->bmax[a];
     }
     fn.lo_ref = lo; fn.hi_ref = hi; fn.axis = (uint32_t)n->axis; fn.pad = 0;
     return me;

@@ -25,13 +25,11 @@ PT_REF_START_MASK = 0x03FFFFFF
 
 
 class FlatNode(C.Structure):
-    _fields_ = [("lo_min", C.c_float * 3), ("lo_max", C.c_float * 3), ("hi_min", C.c_float * 3),
-                ("hi_max", C.c_float * 3), ("lo_ref", C.c_uint32), ("hi_ref", C.c_uint32),
+    _fields_ = [("lo", C.c_float * 6), ("hi", C.c_float * 6), ("lo_ref", C.c_uint32), ("hi_ref", C.c_uint32),
                 ("axis", C.c_uint32), ("pad", C.c_uint32)]
 
 
-NODE_DTYPE = np.dtype([("lo_min", "<f4", (3,)), ("lo_max", "<f4", (3,)), ("hi_min", "<f4", (3,)),
-                       ("hi_max", "<f4", (3,)), ("lo_ref", "<u4"), ("hi_ref", "<u4"), ("axis", "<u4"),
+NODE_DTYPE = np.dtype([("lo", "<f4", (3, 2)), ("hi", "<f4", (3, 2)), ("lo_ref", "<u4"), ("hi_ref", "<u4"), ("axis", "<u4"),
                        ("pad", "<u4")])
 ISECT_DTYPE = np.dtype([("p0", "<f4", (3,)), ("e1", "<f4", (3,)), ("e2", "<f4", (3,)), ("mesh_index", "<u4"),
                         ("leaf_count", "<u4"), ("leaf_remaining", "<u4")])

@@ -22,7 +22,7 @@ struct CpuMem {
     const pt_tri_isect* tris;
     void load_node(uint32_t i, ptc::NodeData& n) const {
         const pt_flat_node& s = nodes[i];
-        for (int k = 0; k < 3; k++) { n.lo_min[k] = s.lo_min[k]; n.lo_max[k] = s.lo_max[k]; n.hi_min[k] = s.hi_min[k]; n.hi_max[k] = s.hi_max[k]; }
+        for (int k = 0; k < 3; k++) { n.lo[k] = ptc::pt_f2{s.lo[k][0], s.lo[k][1]}; n.hi[k] = ptc::pt_f2{s.hi[k][0], s.hi[k][1]}; }
         n.lo_ref = s.lo_ref; n.hi_ref = s.hi_ref; n.axis = s.axis;
     }
     void load_tri(uint32_t k, ptc::TriData& t) const {
@@ -87,42 +87,51 @@ void wave_sim(const pt_flat_scene* sc, uint64_t n, const float* o, const float* 
         if (p->policy == 1 && nt > 0 && nn > 0) {
             if (nt >= p->tri_threshold) run_node = false; else run_tri = false;
         }
-        bool did_tri[64];
-        for (int i = 0; i < 64; i++) did_tri[i] = false;
-        if (run_tri) {
-            for (int k = 0; k < p->tris_per_round; k++) {
-                bool some = false;
-                for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_has_leaf(L[i])) {
-                    ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L[i]), tr);
-                    if (any) ptc::lane_tri<true>(L[i], tr); else ptc::lane_tri<false>(L[i], tr);
-                    s.lane_tri++; some = true; did_tri[i] = true;
-                }
-                if (some) { s.tri_sections++; s.cost += p->c_tri; }
+        auto tri_section = [&](bool* did) {
+            bool some = false;
+            for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_has_leaf(L[i])) {
+                ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L[i]), tr);
+                if (any) ptc::lane_tri<true>(L[i], tr); else ptc::lane_tri<false>(L[i], tr);
+                s.lane_tri++; some = true; if (did) did[i] = true;
             }
-        }
-        if (run_node) {
+            if (some) { s.tri_sections++; s.cost += p->c_tri; }
+        };
+        auto pop_sections = [&](const bool* skip) {
             for (int k = 0; k < p->max_pops; k++) {
                 bool some = false;
                 for (int i = 0; i < 64; i++) {
                     ptc::Lane& l = L[i];
-                    /* a lane that did a triangle this round does not also pop */
-                    if (!active[i] || l.cur != PT_REF_NONE || l.sp <= 0) continue;
+                    if (!active[i] || (skip && skip[i]) || l.cur != PT_REF_NONE || l.sp <= 0) continue;
                     if (any) ptc::lane_pop<true>(l, st[i]); else ptc::lane_pop<false>(l, st[i]);
                     s.lane_pop++; some = true;
-                    if (!ptc::lane_has_leaf(l) && !ptc::lane_has_node(l)) s.lane_pop_culled++;
+                    if (l.cur == PT_REF_NONE) s.lane_pop_culled++;
                 }
                 if (some) { s.pop_sections++; s.cost += p->c_pop; }
             }
+        };
+        auto node_section = [&](const bool* skip) {
             bool some = false;
             for (int i = 0; i < 64; i++) {
                 ptc::Lane& l = L[i];
-                if (!active[i] || did_tri[i] || !ptc::lane_has_node(l)) continue;
+                if (!active[i] || (skip && skip[i]) || !ptc::lane_has_node(l)) continue;
                 ptc::NodeData nd; mem.load_node(l.cur, nd);
                 if (any) { if (l.tame) ptc::lane_node<true, true>(l, nd, st[i]); else ptc::lane_node<true, false>(l, nd, st[i]); }
                 else { if (l.tame) ptc::lane_node<false, true>(l, nd, st[i]); else ptc::lane_node<false, false>(l, nd, st[i]); }
                 s.lane_node++; some = true;
             }
             if (some) { s.node_sections++; s.cost += p->c_node; }
+        };
+        bool did_tri[64];
+        for (int i = 0; i < 64; i++) did_tri[i] = false;
+        if (p->policy == 2) {        /* triangles, pops, then nodes (second load group), pops */
+            tri_section(nullptr); pop_sections(nullptr); node_section(nullptr); pop_sections(nullptr);
+        } else if (p->policy == 3) { /* nodes, pops, then triangles (second load group), pops */
+            node_section(nullptr); pop_sections(nullptr); tri_section(nullptr); pop_sections(nullptr);
+        } else if (p->policy == 4) { /* one load group; kernel order: triangle or node, then pops */
+            tri_section(did_tri); node_section(did_tri); pop_sections(nullptr);
+        } else {
+            if (run_tri) tri_section(did_tri);
+            if (run_node) { pop_sections(did_tri); node_section(did_tri); }
         }
         for (int i = 0; i < 64; i++) if (active[i] && ptc::lane_finished(L[i])) active[i] = false;
         if (starting) {

@@ -19,7 +19,7 @@ struct CpuMem {
     const pt_tri_isect* tris;
     void load_node(uint32_t i, ptc::NodeData& n) const {
         const pt_flat_node& s = nodes[i];
-        for (int k = 0; k < 3; k++) { n.lo_min[k] = s.lo_min[k]; n.lo_max[k] = s.lo_max[k]; n.hi_min[k] = s.hi_min[k]; n.hi_max[k] = s.hi_max[k]; }
+        for (int k = 0; k < 3; k++) { n.lo[k] = ptc::pt_f2{s.lo[k][0], s.lo[k][1]}; n.hi[k] = ptc::pt_f2{s.hi[k][0], s.hi[k][1]}; }
         n.lo_ref = s.lo_ref; n.hi_ref = s.hi_ref; n.axis = s.axis;
     }
     void load_tri(uint32_t k, ptc::TriData& t) const {
