@@ -39,6 +39,7 @@ extern "C" {
 #define PT_MAX_TRIANGLES   ((1u << 26) - 64u)
 #define PT_MAX_TREE_DEPTH  20      /* interior levels above any leaf; reference caps at 19 (kdtree.cpp:13) */
 #define PT_MAX_LIGHTS      16
+#define PT_MAX_RAYS_PER_CALL 0xf0000000ull  /* one ray-cast call; the 32-bit queue head needs headroom above it */
 
 /* One interior node of the reference's tree (kdTreeNode, kdtree.h:19-36), holding the
  * AABBs of BOTH children so a visit needs one 64-byte load.  The node's own box lives in

@@ -77,6 +77,9 @@ struct RaySoAW {
 #ifndef TRACE_CHUNK
 #define TRACE_CHUNK 64     /* fewest rays a wave takes from the queue per atomic */
 #endif
+#ifndef TRACE_MIN_CHUNKS_PER_WAVE
+#define TRACE_MIN_CHUNKS_PER_WAVE 16u /* chunks grow only while every wave still gets this many on average */
+#endif
 #ifndef REFILL_MIN
 #define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
 #endif
@@ -156,7 +159,7 @@ struct TraceArgs {
     RaySoA rays;
     const uint32_t* d_count; /* number of work items = *d_count * count_mul, in device memory */
     uint32_t count_mul;
-    uint32_t* d_next_chunk;  /* atomic head of the ray queue, in chunks; zero at launch */
+    uint32_t* d_next_chunk;  /* atomic head of the ray queue: chunks handed out beyond one per wave; zero at launch */
     int32_t* out_idx;        /* CLOSEST_MESH: four separate arrays (the C ABI's layout) */
     float *out_t, *out_u, *out_v;
     float4* out_hit;         /* CLOSEST_FLAT: one 16-byte record {position bits, t, u, v} per ray, so a
@@ -206,14 +209,23 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     float dist = 0.0f;
     uint32_t pool_next = 0, pool_end = 0; /* wave-uniform: unclaimed rays of the current chunk */
     bool exhausted = false;               /* wave-uniform: the queue has no more chunks */
-    /* Chunk size: TRACE_CHUNK rays for short queues (finer balance in the tail), growing to 16x
-     * that for long ones so that the queue head sees far fewer atomics than it can sustain. */
+    /* The ray queue is handed out in chunks of consecutive rays: TRACE_CHUNK rays for short
+     * queues (finer balance in the tail, and the rays in flight stay close together), growing
+     * to 16x that while every wave still gets TRACE_MIN_CHUNKS_PER_WAVE chunks on average, so
+     * that a long queue does not saturate the atomic (one address sustains about 90 M/s).
+     * A wave's first chunk is the one with its own number; later ones come from the shared
+     * head, which therefore starts after the last wave's.  So a launch does not open with
+     * every wave queueing on one atomic, and the waves of an almost empty launch leave at once.
+     * (Measured and rejected: reading the head before bumping it, to spare the last failing
+     * atomic per wave -- a device-scope load per chunk made the kernel four times slower; and
+     * chunk sizes that shrink with the work left -- faster on coherent camera rays, slower on
+     * everything else.) */
+    const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / 64);
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (TRACE_BLOCK / 64) + (threadIdx.x >> 6));
     uint32_t chunk = TRACE_CHUNK;
-    {
-        const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
-        while (chunk < 16u * TRACE_CHUNK && (uint64_t)chunk * 2u * 16u * waves <= n) chunk *= 2u;
-    }
+    while (chunk < 16u * TRACE_CHUNK && (uint64_t)chunk * 2u * TRACE_MIN_CHUNKS_PER_WAVE * n_waves <= n) chunk *= 2u;
     const uint32_t total_chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
+    bool first_chunk = true;              /* wave-uniform */
     const bool scene_tame = root_is_tame(sc.root);
 
     while (true) {
@@ -225,9 +237,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
                 if (pool_next >= pool_end) {
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(a.d_next_chunk, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
+                    uint32_t c = wave_id;
+                    if (!first_chunk) {
+                        if (lane == 0) c = atomicAdd(a.d_next_chunk, 1u);
+                        c = n_waves + __builtin_amdgcn_readfirstlane(c);
+                    }
+                    first_chunk = false;
                     if (c < total_chunks) {
                         const uint64_t first = (uint64_t)c * chunk;
                         pool_next = (uint32_t)first;
@@ -821,7 +836,7 @@ int pt_raycast_closest_dev(pt_scene* s, uint64_t n, const float* ox, const float
     if (!s) return fail(PT_ERR_INVALID, "null scene");
     if (n == 0) return PT_OK;
     if (!ox || !oy || !oz || !dx || !dy || !dz || !idx || !t || !u || !v) return fail(PT_ERR_INVALID, "null array");
-    if (n >= 0xffffff00ull) return fail(PT_ERR_LIMIT, "more than 2^32-256 rays in one call");
+    if (n > PT_MAX_RAYS_PER_CALL) return fail(PT_ERR_LIMIT, "more than PT_MAX_RAYS_PER_CALL rays in one call");
     int rc = set_device(s);
     if (rc) return rc;
     if (s->n_tris == 0) return fill_miss_closest(s, n, idx, t, u, v);
@@ -839,7 +854,7 @@ int pt_raycast_shadow_dev(pt_scene* s, uint64_t n, const float* ox, const float*
     if (!s) return fail(PT_ERR_INVALID, "null scene");
     if (n == 0) return PT_OK;
     if (!ox || !oy || !oz || !dx || !dy || !dz || !dist || !vis) return fail(PT_ERR_INVALID, "null array");
-    if (n >= 0xffffff00ull) return fail(PT_ERR_LIMIT, "more than 2^32-256 rays in one call");
+    if (n > PT_MAX_RAYS_PER_CALL) return fail(PT_ERR_LIMIT, "more than PT_MAX_RAYS_PER_CALL rays in one call");
     int rc = set_device(s);
     if (rc) return rc;
     if (s->n_tris == 0) { HIP_TRY(hipMemsetAsync(vis, 1, n, s->stream)); return PT_OK; }
