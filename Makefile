@@ -37,12 +37,16 @@ $(LIBDIR)/libpt_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
 
 # The reference's C++ scene/render API on top of the C ABI, and its command-line front end.
-render: $(LIBDIR)/libpt_render.so $(PKG)/bin/cli_render
+render: $(LIBDIR)/libpt_render.so $(PKG)/bin/cli_render $(PKG)/bin/animate
 $(LIBDIR)/libpt_render.so: $(PKG)/host/render_api.cpp include/pt_render.h include/pt_hip.h include/pt_host.h $(LIBDIR)/libpt_host.so $(LIBDIR)/libpt_hip.so
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(PKG)/host/render_api.cpp -L$(LIBDIR) -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN'
 $(PKG)/bin/cli_render: $(PKG)/host/cli_render.cpp include/pt_render.h $(LIBDIR)/libpt_render.so
 	mkdir -p $(PKG)/bin
 	$(CXX) $(HOSTFLAGS) -o $@ $(PKG)/host/cli_render.cpp -L$(LIBDIR) -lpt_render -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,$(ROCM)/lib
+
+$(PKG)/bin/animate: $(PKG)/host/animate.cpp include/pt_render.h $(LIBDIR)/libpt_render.so
+	mkdir -p $(PKG)/bin
+	$(CXX) $(HOSTFLAGS) -o $@ $(PKG)/host/animate.cpp -L$(LIBDIR) -lpt_render -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,$(ROCM)/lib
 
 # Lane-level emulation of the device traversal on the CPU (tests only).
 native-tests: tests/native/_build/libtraverse_emul.so

@@ -523,6 +523,7 @@ void RenderEngine::zero() {
     sync();
     total_passes_issued = 0;
     total_passes_completed = 0;
+    samples_issued.clear(); /* a zeroed canvas starts its sample stream again: frames are reproducible */
     for (auto worker : workers) {
         if (worker->integrator->film) pt_film_zero(worker->integrator->film);
         worker->integrator->canvas->zero();
