@@ -182,6 +182,9 @@ int  pt_film_zero(pt_film* f);                         /* Canvas::zero, canvas.c
 float* pt_film_device_ptr(pt_film* f);
 /* Copies out Canvas::pixels (W*H*3) and Canvas::per_pixel_passes (W*H); waits for rendering. */
 int  pt_film_read(pt_film* f, float* rgb_sum, int32_t* per_pixel_passes);
+/* Adds host accumulators of the same size into the film (Canvas::add_from with a host Canvas,
+ * canvas.cpp:47-52): how a render resumes from accumulators saved earlier. */
+int  pt_film_add(pt_film* f, const float* rgb_sum, const int32_t* per_pixel_passes);
 
 /* Integrator::perform_pass (integrator.cpp:211-275) for every listed tile pass, as a
  * wavefront path tracer.  Asynchronous unless stats != NULL (then it waits and fills stats).

@@ -161,6 +161,11 @@ public:
     void get_pixel(int x, int y, uint8_t* dest);
     void add_from(Canvas* other);
     int save(std::string path); /* 8-bit RGB PNG; 0 on success, -1 on failure */
+    /* The accumulators themselves (energy sums and pass counts, no tone mapping), so that a
+     * long render can be stopped and continued; 0 on success, -1 on failure (load: also when
+     * the file's size differs from this canvas). */
+    int save_accumulators(std::string path);
+    int load_accumulators(std::string path);
 };
 
 struct RenderEngine;
@@ -228,6 +233,11 @@ struct RenderEngine { /* integrator.h:91-127 */
     void kill_workers();
     int rebuild_master_canvas();
     void zero();
+    /* Continues a render: zero(), then the canvas' accumulators become the first worker's film
+     * and every rectangle's sample stream starts after the samples the canvas already holds
+     * (its largest pass count).  0 on success. */
+    int resume_from(Canvas* saved);
+    uint32_t sample_base;
 };
 
 class ProgressReporter { /* visualizer.h:10-15 */

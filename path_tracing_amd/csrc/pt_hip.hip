@@ -589,6 +589,15 @@ __global__ void k_film_split(const float4* film, size_t n, float* rgb, int32_t* 
     passes[i] = (int32_t)v.w;
 }
 
+__global__ void k_film_add(float4* film, size_t n, const float* rgb, const int32_t* passes) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = film[i];
+    v.x += rgb[3 * i]; v.y += rgb[3 * i + 1]; v.z += rgb[3 * i + 2];
+    v.w += (float)passes[i];
+    film[i] = v;
+}
+
 /* --------------------------------------------------------------- host side */
 
 struct TimedLaunch { int cls; hipEvent_t a, b; };
@@ -1147,6 +1156,23 @@ int pt_film_read(pt_film* f, float* rgb_sum, int32_t* passes) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rgb_sum, d_rgb.p, n * 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(passes, d_p.p, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+int pt_film_add(pt_film* f, const float* rgb_sum, const int32_t* passes) {
+    if (!f || !rgb_sum || !passes) return fail(PT_ERR_INVALID, "null argument");
+    pt_scene* s = f->scene;
+    int rc = set_device(s);
+    if (rc) return rc;
+    size_t n = (size_t)f->width * f->height;
+    DevBuf d_rgb, d_p;
+    rc = d_rgb.alloc(n * 12); if (rc) return rc;
+    rc = d_p.alloc(n * 4); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_rgb.p, rgb_sum, n * 12, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(d_p.p, passes, n * 4, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_film_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, f->d_film, n, (const float*)d_rgb.p, (const int32_t*)d_p.p);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PT_OK;
 }

@@ -4,8 +4,9 @@
  *
  * The reference parses with Boost.program_options; this parser accepts the same spellings
  * (--name value, --name=value, one positional STL path) without that dependency.  Added:
- * --gpus N (same as --threads: how many GPUs to use, 0 = all) and --seed N.  --display is
- * accepted and ignored (there is no SDL preview).
+ * --gpus N (same as --threads: how many GPUs to use, 0 = all), --seed N, and --checkpoint FILE /
+ * --resume FILE (stop a long render and continue it later from its accumulators).  --display
+ * is accepted and ignored (there is no SDL preview).
  */
 #include <cmath>
 #include <cstdlib>
@@ -33,6 +34,8 @@ static const Option OPTIONS[] = {
     {"threads", "0", "Number of GPUs. (0 for all)", false},
     {"gpus", nullptr, "Same as --threads.", false},
     {"seed", "1", "Seed of the random stream.", false},
+    {"checkpoint", nullptr, "Also write the accumulators (energy sums, pass counts) to this file.", false},
+    {"resume", nullptr, "Continue from accumulators written by --checkpoint (same size, same seed).", false},
     {"angle", "1", "Camera angle.", false},
     {"camera-altitude", "0.2", "Camera altitude.", false},
     {"camera-distance", "5", "Camera distance from (origin + camera_altitude * zhat).", false},
@@ -119,6 +122,15 @@ int main(int argc, char** argv) {
     engine->tile_width = atoi(vm["tile-width"].c_str());
     engine->tile_height = atoi(vm["tile-height"].c_str());
 
+    if (vm.count("resume")) {
+        Canvas saved(engine->width, engine->height);
+        if (saved.load_accumulators(vm["resume"]) != 0 || engine->resume_from(&saved) != 0) {
+            cout << "Couldn't resume from: " << vm["resume"] << endl;
+            return 1;
+        }
+        cout << "Resumed after " << engine->sample_base << " samples from: " << vm["resume"] << endl;
+    }
+
     ProgressReporter* pr = new ProgressBar(engine);
     pr->init();
     int samples_count = atoi(vm["samples"].c_str());
@@ -135,6 +147,10 @@ int main(int argc, char** argv) {
     string output_path = vm["output"];
     if (engine->master_canvas->save(output_path) != 0) { cout << "Couldn't write: " << output_path << endl; return 1; }
     cout << "Wrote to: " << output_path << endl;
+    if (vm.count("checkpoint")) {
+        if (engine->master_canvas->save_accumulators(vm["checkpoint"]) != 0) { cout << "Couldn't write: " << vm["checkpoint"] << endl; return 1; }
+        cout << "Accumulators written to: " << vm["checkpoint"] << endl;
+    }
     delete engine;
     delete scene;
     return 0;

@@ -228,6 +228,38 @@ static void png_chunk(FILE* fp, const char* type, const unsigned char* data, siz
 
 /* 8-bit RGB, no interlace, like the reference's libpng call (canvas.cpp:55-131); written with
  * zlib alone.  Returns 0 on success and -1 on any failure, never throws. */
+static const char ACC_MAGIC[8] = {'P', 'T', 'A', 'C', 'C', '0', '1', 0};
+
+int Canvas::save_accumulators(string path) {
+    FILE* fp = fopen(path.c_str(), "wb");
+    if (!fp) return -1;
+    int32_t dims[2] = {width, height};
+    bool ok = fwrite(ACC_MAGIC, 1, 8, fp) == 8 && fwrite(dims, 4, 2, fp) == 2;
+    for (int i = 0; ok && i < size; i++) {
+        float rgb[3] = {pixels[i](0), pixels[i](1), pixels[i](2)};
+        ok = fwrite(rgb, 4, 3, fp) == 3;
+    }
+    ok = ok && fwrite(per_pixel_passes, sizeof(int), (size_t)size, fp) == (size_t)size;
+    return (fclose(fp) == 0 && ok) ? 0 : -1;
+}
+
+int Canvas::load_accumulators(string path) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) return -1;
+    char magic[8];
+    int32_t dims[2];
+    bool ok = fread(magic, 1, 8, fp) == 8 && memcmp(magic, ACC_MAGIC, 8) == 0 && fread(dims, 4, 2, fp) == 2 &&
+              dims[0] == width && dims[1] == height;
+    for (int i = 0; ok && i < size; i++) {
+        float rgb[3];
+        ok = fread(rgb, 4, 3, fp) == 3;
+        if (ok) pixels[i] = Color(rgb[0], rgb[1], rgb[2]);
+    }
+    ok = ok && fread(per_pixel_passes, sizeof(int), (size_t)size, fp) == (size_t)size;
+    fclose(fp);
+    return ok ? 0 : -1;
+}
+
 int Canvas::save(string path) {
     FILE* fp = fopen(path.c_str(), "wb");
     if (!fp) return -1;
@@ -431,6 +463,7 @@ RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_widt
     total_passes_issued = 0;
     total_passes_completed = 0;
     semaphore_passes_pending = 0;
+    sample_base = 0;
     int n = get_optimal_thread_count();
     for (int i = 0; i < n; i++) workers.push_back(new RenderThread(this, i));
     if (workers.empty()) cerr << "RenderEngine: no GPU available (" << pt_last_error() << ")" << endl;
@@ -452,7 +485,7 @@ void RenderEngine::issue_pass_desc(PassDescriptor desc) {
     if (workers.empty()) return;
     PassDescriptor key = desc;
     key.clamp_bounds(width, height);
-    uint32_t sample = samples_issued[make_pair(make_pair(key.start_x, key.start_y), make_pair(key.width, key.height))]++;
+    uint32_t sample = sample_base + samples_issued[make_pair(make_pair(key.start_x, key.start_y), make_pair(key.width, key.height))]++;
     int worker = (total_passes_issued++) % (int)workers.size();
     workers[(size_t)worker]->send_message(RenderMessage({false, desc, sample}));
     semaphore_passes_pending++;
@@ -524,10 +557,29 @@ void RenderEngine::zero() {
     total_passes_issued = 0;
     total_passes_completed = 0;
     samples_issued.clear(); /* a zeroed canvas starts its sample stream again: frames are reproducible */
+    sample_base = 0;
     for (auto worker : workers) {
         if (worker->integrator->film) pt_film_zero(worker->integrator->film);
         worker->integrator->canvas->zero();
     }
+}
+
+int RenderEngine::resume_from(Canvas* saved) {
+    if (!saved || saved->width != width || saved->height != height || workers.empty()) return -1;
+    zero();
+    Integrator* in = workers[0]->integrator;
+    if (!in->film) return -1;
+    vector<float> rgb((size_t)saved->size * 3);
+    vector<int32_t> passes((size_t)saved->size);
+    int most = 0;
+    for (int i = 0; i < saved->size; i++) {
+        for (int c = 0; c < 3; c++) rgb[(size_t)i * 3 + c] = saved->pixels[i](c);
+        passes[(size_t)i] = saved->per_pixel_passes[i];
+        most = max(most, saved->per_pixel_passes[i]);
+    }
+    if (pt_film_add(in->film, rgb.data(), passes.data()) != PT_OK) return -1;
+    sample_base = (uint32_t)most;
+    return 0;
 }
 
 /* ------------------------------------------------------------ progress bar */

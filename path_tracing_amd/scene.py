@@ -260,3 +260,11 @@ class Film:
         passes = np.empty((self.height, self.width), dtype=np.int32)
         check(native.hip_lib().pt_film_read(self.h, _p(rgb), _p(passes)), "pt_film_read")
         return rgb, passes
+
+    def add(self, rgb, passes):
+        """Adds host accumulators (as returned by read()) into the film."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        passes = np.ascontiguousarray(passes, dtype=np.int32)
+        if rgb.shape != (self.height, self.width, 3) or passes.shape != (self.height, self.width):
+            raise ValueError("accumulator shapes do not match the film")
+        check(native.hip_lib().pt_film_add(self.h, _p(rgb), _p(passes)), "pt_film_add")

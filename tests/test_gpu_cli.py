@@ -79,3 +79,38 @@ def test_animate_frames_match_single_renders(tmp_path, scene_small):
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout + res.stderr
         assert np.array_equal(frames[f], _read_png(single)), f
+
+
+def test_checkpoint_and_resume(tmp_path, scene_small):
+    """Accumulator dump and resume: 6 samples, stopped after 4 and continued, give the picture
+    of 6 samples in one go (pass counts equal; energy sums differ only by float summation order)."""
+    stl = str(tmp_path / "standin.stl")
+    pta.meshgen.write_stl(stl, scene_small.tris)
+    base = [CLI, stl, "--width", "160", "--height", "120", "--dof-aperture", "0.1", "--dof-distance", "4.5", "--seed", "3"]
+    whole, part, cont = (str(tmp_path / n) for n in ("whole.png", "part.png", "cont.png"))
+    acc4, acc6, acc6b = (str(tmp_path / n) for n in ("acc4.bin", "acc6.bin", "acc6b.bin"))
+    for cmd in (base + ["--output", whole, "--samples", "6", "--checkpoint", acc6],
+                base + ["--output", part, "--samples", "4", "--checkpoint", acc4],
+                base + ["--output", cont, "--samples", "2", "--resume", acc4, "--checkpoint", acc6b]):
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout + res.stderr
+    assert "Resumed after 4 samples" in res.stdout
+
+    def load(path):
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"PTACC01\0"
+        w, h = np.frombuffer(raw, "<i4", 2, 8)
+        rgb = np.frombuffer(raw, "<f4", w * h * 3, 16).reshape(h, w, 3)
+        passes = np.frombuffer(raw, "<i4", w * h, 16 + w * h * 12).reshape(h, w)
+        return rgb, passes
+    rgb_a, p_a = load(acc6)
+    rgb_b, p_b = load(acc6b)
+    assert (p_a == 6).all() and (p_b == 6).all()
+    assert np.allclose(rgb_a, rgb_b, rtol=1e-5, atol=1e-5)
+    diff = np.abs(_read_png(whole).astype(int) - _read_png(cont).astype(int))
+    assert diff.max() <= 1
+    assert not np.array_equal(_read_png(part), _read_png(cont))
+    # a checkpoint of another size is refused
+    res = subprocess.run(base[:2] + ["--width", "80", "--height", "60", "--samples", "1", "--resume", acc4,
+                                     "--output", str(tmp_path / "x.png")], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 1 and "Couldn't resume from" in res.stdout

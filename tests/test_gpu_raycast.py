@@ -107,3 +107,19 @@ def test_render_tiling_invariance(scene_small):
     tiled, passes = film.read()
     assert (passes == S).all()
     assert np.array_equal(full.view(np.uint32), tiled.view(np.uint32))
+
+
+def test_film_add_restores_accumulators(scene_tiny):
+    """pt_film_add: a film that is read, zeroed and given its accumulators back is unchanged."""
+    gpu = pta.GpuScene(scene_tiny.host, 0)
+    film = pta.Film(gpu, 64, 48)
+    film.render(pta.cli_camera(), pta.cli_lights(), [(0, 0, -1, -1, 0, 3)], seed=5)
+    rgb, passes = film.read()
+    assert (passes == 3).all() and rgb.max() > 0
+    film.zero()
+    film.add(rgb, passes)
+    film.add(rgb, passes)
+    rgb2, passes2 = film.read()
+    assert np.array_equal(passes2, 2 * passes) and np.array_equal(rgb2, rgb + rgb)
+    with pytest.raises(ValueError):
+        film.add(rgb[:10], passes[:10])
