@@ -65,9 +65,9 @@ typedef struct pt_tri_isect {
  * (integrator.cpp:66-74, utils.cpp:165-170). */
 typedef struct pt_tri_shade {
     float normal[3];  float plane;   /* Triangle::normal; mean of normal.dot(points[i]) */
-    float base_n[3];  float pad0;    /* base_normal */
-    float u_n[3];     float pad1;    /* u_normal    */
-    float v_n[3];     float pad2;    /* v_normal    */
+    float base_n[3];  float d1_x;    /* base_normal; d1 = edge01.normalized() (integrator.cpp:82), */
+    float u_n[3];     float d1_y;    /* u_normal;    one component per record slot              */
+    float v_n[3];     float d1_z;    /* v_normal                                                */
 } pt_tri_shade;                      /* 64 bytes */
 
 typedef struct pt_flat_scene {
@@ -148,7 +148,17 @@ typedef struct pt_camera {
     float plane_of_focus_distance;
     float dof_dispersion;
     float sky_color[3];
+    uint32_t bounce_mode;            /* PT_BOUNCE_MIRROR or PT_BOUNCE_LAMBERT */
 } pt_camera;
+
+/* What the bounce ray of a path vertex is (integrator.cpp:76-108).
+ * PT_BOUNCE_MIRROR: the reflected direction -- the reference as it stands (:104 overwrites the
+ * scattered direction).  This is the mode every parity claim is about.
+ * PT_BOUNCE_LAMBERT: the direction :79-84 compute before :104 replaces it (a unit-sphere sample
+ * folded onto the triangle's side, in the frame {normal, edge01, normal x edge01}); the
+ * reference's "diffuse" look, kept as a flagged extension. */
+#define PT_BOUNCE_MIRROR  0u
+#define PT_BOUNCE_LAMBERT 1u
 
 typedef struct pt_light {        /* Light, integrator.h:15-18 */
     float position[3];

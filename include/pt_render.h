@@ -133,6 +133,7 @@ struct Scene { /* integrator.h:20-33 */
     Real plane_of_focus_distance;
     Real dof_dispersion;
     Color sky_color;
+    bool lambertian_bounces; /* extension, default false: bounce by integrator.cpp:79-84 instead of the mirror direction of :104 */
     Scene(std::string path);
     ~Scene();
 };

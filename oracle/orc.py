@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 class Camera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3),
                 ("image_plane_width", C.c_float), ("plane_of_focus_distance", C.c_float),
-                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3)]
+                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3), ("bounce_mode", C.c_uint32)]
 
 
 class Light(C.Structure):
@@ -81,7 +81,7 @@ def _f32(a):
 
 
 def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of_focus_distance=1.0,
-                dof_dispersion=0.0, sky_color=(0, 0, 0)) -> Camera:
+                dof_dispersion=0.0, sky_color=(0, 0, 0), bounce_mode=0) -> Camera:
     c = Camera()
     c.origin[:] = [float(np.float32(x)) for x in origin]
     c.direction[:] = [float(np.float32(x)) for x in direction]
@@ -90,6 +90,7 @@ def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of
     c.plane_of_focus_distance = plane_of_focus_distance
     c.dof_dispersion = dof_dispersion
     c.sky_color[:] = list(sky_color)
+    c.bounce_mode = bounce_mode   # 0: mirror (the reference as it stands), 1: Lambertian scatter
     return c
 
 
@@ -222,7 +223,7 @@ def philox(ctr, key):
     return out
 
 
-def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0):
+def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0, bounce_mode=0):
     """Camera exactly as the reference's cli_render sets it up (cli_render.cpp:92-100)."""
     f32 = np.float32
     a = f32(angle)
@@ -235,7 +236,7 @@ def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture
     direction = direction / np.sqrt(f32(z), dtype=np.float32)
     origin = origin + np.array([0.0, 0.0, altitude], dtype=np.float32)
     return make_camera(origin, direction, (0, 0, 1), image_plane_width=0.75, plane_of_focus_distance=dof_distance,
-                       dof_dispersion=dof_aperture)
+                       dof_dispersion=dof_aperture, bounce_mode=bounce_mode)
 
 
 def cli_lights():

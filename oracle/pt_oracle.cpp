@@ -535,6 +535,7 @@ struct PathCtx {
     V3 sky;
     uint64_t seed;
     uint32_t pixel, sample;
+    uint32_t bounce_mode;
     uint64_t closest_casts, shadow_casts;
     Counters* work_closest; /* optional: box/triangle tests spent on closest-hit casts */
     Counters* work_shadow;  /* ... and on shadow casts */
@@ -562,7 +563,19 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
         /* :79-84 draw a scatter direction that :104 then replaces by the mirror direction; the
          * draws only advance the reference's engine and have no counterpart in a counter-based
          * stream.  Ray's constructor normalises the (already unit) direction again. */
-        Ray scattered = make_ray(hit, reflection);
+        V3 scatter_direction = reflection;
+        if (ctx.bounce_mode == 1) {
+            /* :79-84 as written, kept instead of being overwritten at :104.  sample_unit_sphere
+             * (utils.cpp:177-185) is three standard normals, normalised; stream 1 + depth. */
+            uint32_t sw[4];
+            rng_words(ctx.seed, ctx.pixel, ctx.sample, 1u + (uint32_t)depth, sw);
+            V3 local = normalized(mk(normal_from_word(sw[0]), normal_from_word(sw[1]), normal_from_word(sw[2])));
+            local.x = fabsf(local.x);                                   /* :80 */
+            V3 d1 = normalized(tr.e1);                                  /* :82 */
+            V3 d2 = cross(tr.normal, d1);                               /* :83 */
+            scatter_direction = (local.x * tr.normal + local.y * d1) + local.z * d2; /* :84 */
+        }
+        Ray scattered = make_ray(hit, scatter_direction);
         float w = (float)((1.0 / 1) * 0.8);
         energy = energy + w * cast_ray(ctx, scattered, recursions - 1, depth + 1); /* :107 */
     }
@@ -789,6 +802,7 @@ static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_lig
         PathCtx ctx;
         ctx.scene = &s->s; ctx.lights = lights; ctx.n_lights = n_lights;
         ctx.sky = mk(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
+        ctx.bounce_mode = cam->bounce_mode;
         ctx.seed = seed; ctx.closest_casts = 0; ctx.shadow_casts = 0;
         Counters wc, ws;
         ctx.work_closest = count_work ? &wc : nullptr;

@@ -34,6 +34,8 @@ typedef struct orc_camera {
     float plane_of_focus_distance;
     float dof_dispersion;
     float sky_color[3];
+    uint32_t bounce_mode; /* 0: mirror bounce (the reference as it stands, integrator.cpp:104);
+                             1: the Lambertian scatter of :79-84 without :104 (flagged extension) */
 } orc_camera;
 
 typedef struct orc_light {

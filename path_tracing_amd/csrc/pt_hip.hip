@@ -511,6 +511,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             ShadeTri st;
             st.normal = v3(s0.x, s0.y, s0.z); st.plane = s0.w;
             st.base_n = v3(s1.x, s1.y, s1.z); st.u_n = v3(s2.x, s2.y, s2.z); st.v_n = v3(s3.x, s3.y, s3.z);
+            st.d1 = v3(s1.w, s2.w, s3.w);
             V3f o = v3(b.q[cur].ox[i], b.q[cur].oy[i], b.q[cur].oz[i]);
             V3f d = v3(b.q[cur].dx[i], b.q[cur].dy[i], b.q[cur].dz[i]);
             SurfaceFrame f = surface_frame(o, d, hrec.y, hrec.z, hrec.w, st);
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             b.qpath[nxt][slot] = path;
             if (!last_depth) {
                 V3f bo, bd;
-                bounce_ray(f, bo, bd);
+                if (cam.bounce_mode == PT_BOUNCE_LAMBERT) bounce_ray_lambert(f, st, seed, pixel, sample, depth, bo, bd);
+                else bounce_ray(f, bo, bd);
                 b.q[nxt].ox[slot] = bo.x; b.q[nxt].oy[slot] = bo.y; b.q[nxt].oz[slot] = bo.z;
                 b.q[nxt].dx[slot] = bd.x; b.q[nxt].dy[slot] = bd.y; b.q[nxt].dz[slot] = bd.z;
                 b.thr[path] = 0.8f * thr; /* reference integrator.cpp:107 */
@@ -1027,6 +1029,7 @@ static void fill_cam(CamParams& c, const pt_camera* cam, int width, int height) 
     c.plane_of_focus_distance = cam->plane_of_focus_distance;
     c.dof_dispersion = cam->dof_dispersion;
     c.sky = v3(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
+    c.bounce_mode = cam->bounce_mode;
 }
 
 /* Renders one batch (already clamped, grouped and numbered) with no host round trip. */
@@ -1182,6 +1185,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     if (!f || !cam || n_passes < 0 || (n_passes > 0 && !passes) || n_lights < 0 || (n_lights > 0 && !lights))
         return fail(PT_ERR_INVALID, "bad argument");
     if (n_lights > PT_MAX_LIGHTS) return fail(PT_ERR_LIMIT, "more than PT_MAX_LIGHTS lights");
+    if (cam->bounce_mode > PT_BOUNCE_LAMBERT) return fail(PT_ERR_INVALID, "unknown bounce_mode");
     pt_scene* s = f->scene;
     int rc = set_device(s);
     if (rc) return rc;

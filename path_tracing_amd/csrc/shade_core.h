@@ -40,6 +40,7 @@ struct CamParams {
     float image_plane_width, plane_of_focus_distance, dof_dispersion;
     V3f sky;
     int width, height;
+    uint32_t bounce_mode;
 };
 
 PT_HD void cam_basis(CamParams& c, V3f scene_up) {
@@ -80,6 +81,7 @@ PT_HD void camera_ray_jittered(const CamParams& c, int x, int y, uint32_t sample
 struct ShadeTri {
     V3f normal; float plane;
     V3f base_n, u_n, v_n;
+    V3f d1; /* edge01.normalized() */
 };
 
 struct SurfaceFrame {
@@ -102,6 +104,21 @@ PT_HD SurfaceFrame surface_frame(V3f o, V3f d, float t, float u, float v, const 
 
 /* The bounce ray: Ray(hit, reflection), whose constructor normalises again (:104-105). */
 PT_HD void bounce_ray(const SurfaceFrame& f, V3f& o, V3f& d) { o = f.hit; d = vunit(f.refl); }
+
+/* The bounce ray of the Lambertian mode (:79-84, i.e. the reference without :104): a unit-sphere
+ * sample (utils.cpp:177-185: three standard normals, normalised) with its first component
+ * made non-negative, taken in the triangle's frame {normal, d1, normal x d1}.  Stream 1 + depth
+ * of the path's random stream supplies the three normals. */
+PT_HD void bounce_ray_lambert(const SurfaceFrame& f, const ShadeTri& tr, uint64_t seed, uint32_t pixel, uint32_t sample,
+                              uint32_t depth, V3f& o, V3f& d) {
+    Rng4 w = rng_block(seed, pixel, sample, 1u + depth);
+    V3f local = vunit(v3(normal_from_word(w.w[0]), normal_from_word(w.w[1]), normal_from_word(w.w[2])));
+    local.x = __builtin_fabsf(local.x);
+    V3f d2 = vcross(tr.normal, tr.d1);
+    V3f scatter = vadd(vadd(vscale_l(local.x, tr.normal), vscale_l(local.y, tr.d1)), vscale_l(local.z, d2));
+    o = f.hit;
+    d = vunit(scatter);
+}
 
 struct LightSample {
     V3f dir;      /* normalised shadow-ray direction (Ray constructor) */

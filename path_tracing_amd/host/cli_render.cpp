@@ -34,6 +34,7 @@ static const Option OPTIONS[] = {
     {"threads", "0", "Number of GPUs. (0 for all)", false},
     {"gpus", nullptr, "Same as --threads.", false},
     {"seed", "1", "Seed of the random stream.", false},
+    {"lambertian", nullptr, "Bounce diffusely (reference integrator.cpp:79-84) instead of mirror-like.", true},
     {"checkpoint", nullptr, "Also write the accumulators (energy sums, pass counts) to this file.", false},
     {"resume", nullptr, "Continue from accumulators written by --checkpoint (same size, same seed).", false},
     {"angle", "1", "Camera angle.", false},
@@ -115,6 +116,7 @@ int main(int argc, char** argv) {
     scene->main_camera.origin += Vec(0.0, 0.0, atof(vm["camera-altitude"].c_str()));
     scene->plane_of_focus_distance = atof(vm["dof-distance"].c_str());
     scene->dof_dispersion = atof(vm["dof-aperture"].c_str());
+    scene->lambertian_bounces = vm.count("lambertian") != 0;
 
     auto engine = new RenderEngine(atoi(vm["width"].c_str()), atoi(vm["height"].c_str()), scene);
     if (engine->workers.empty()) { cout << "No GPU available." << endl; return 1; }

@@ -159,6 +159,7 @@ Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integr
     plane_of_focus_distance = 1.0;
     dof_dispersion = 0.0;
     sky_color = Vec(0, 0, 0);
+    lambertian_bounces = false;
     mesh = nullptr; lights = nullptr; tree = nullptr;
     pth_scene* built = pth_scene_from_stl(path.c_str(), 0);
     if (built == nullptr) {
@@ -297,6 +298,7 @@ static void fill_camera(pt_camera& c, const Scene* s) {
     c.image_plane_width = s->camera_image_plane_width;
     c.plane_of_focus_distance = s->plane_of_focus_distance;
     c.dof_dispersion = s->dof_dispersion;
+    c.bounce_mode = s->lambertian_bounces ? PT_BOUNCE_LAMBERT : PT_BOUNCE_MIRROR;
 }
 
 static void fill_lights(vector<pt_light>& out, const Scene* s) {

@@ -356,6 +356,8 @@ void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm,
         ts.base_n[0] = m.vn0[i].x; ts.base_n[1] = m.vn0[i].y; ts.base_n[2] = m.vn0[i].z;
         ts.u_n[0] = un.x; ts.u_n[1] = un.y; ts.u_n[2] = un.z;
         ts.v_n[0] = vn.x; ts.v_n[1] = vn.y; ts.v_n[2] = vn.z;
+        F3 d1 = unit(e1); /* hit_triangle->edge01.normalized(), integrator.cpp:82 */
+        ts.d1_x = d1.x; ts.d1_y = d1.y; ts.d1_z = d1.z;
     }
     mark_leaf_counts(root, f);
     memset(&f.desc, 0, sizeof(f.desc));

@@ -33,8 +33,8 @@ NODE_DTYPE = np.dtype([("lo", "<f4", (3, 2)), ("hi", "<f4", (3, 2)), ("lo_ref", 
                        ("pad", "<u4")])
 ISECT_DTYPE = np.dtype([("p0", "<f4", (3,)), ("e1", "<f4", (3,)), ("e2", "<f4", (3,)), ("mesh_index", "<u4"),
                         ("leaf_count", "<u4"), ("leaf_remaining", "<u4")])
-SHADE_DTYPE = np.dtype([("normal", "<f4", (3,)), ("plane", "<f4"), ("base_n", "<f4", (3,)), ("pad0", "<f4"),
-                        ("u_n", "<f4", (3,)), ("pad1", "<f4"), ("v_n", "<f4", (3,)), ("pad2", "<f4")])
+SHADE_DTYPE = np.dtype([("normal", "<f4", (3,)), ("plane", "<f4"), ("base_n", "<f4", (3,)), ("d1_x", "<f4"),
+                        ("u_n", "<f4", (3,)), ("d1_y", "<f4"), ("v_n", "<f4", (3,)), ("d1_z", "<f4")])
 assert NODE_DTYPE.itemsize == 64 and ISECT_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 64
 
 
@@ -47,7 +47,7 @@ class FlatScene(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3),
                 ("image_plane_width", C.c_float), ("plane_of_focus_distance", C.c_float),
-                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3)]
+                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3), ("bounce_mode", C.c_uint32)]
 
 
 class Light(C.Structure):

@@ -23,7 +23,7 @@ def _f32(a):
 
 
 def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of_focus_distance=1.0,
-                dof_dispersion=0.0, sky_color=(0, 0, 0)) -> Camera:
+                dof_dispersion=0.0, sky_color=(0, 0, 0), bounce_mode=0) -> Camera:
     c = Camera()
     c.origin[:] = [float(np.float32(x)) for x in origin]
     c.direction[:] = [float(np.float32(x)) for x in direction]
@@ -32,6 +32,7 @@ def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of
     c.plane_of_focus_distance = plane_of_focus_distance
     c.dof_dispersion = dof_dispersion
     c.sky_color[:] = list(sky_color)
+    c.bounce_mode = bounce_mode   # 0: mirror (the reference as it stands), 1: Lambertian scatter
     return c
 
 
@@ -43,7 +44,8 @@ def make_lights(lights):
     return arr
 
 
-def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0) -> Camera:
+def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0,
+               bounce_mode=0) -> Camera:
     """Camera as the reference's cli_render derives it from its flags (cli_render.cpp:92-100)."""
     f32 = np.float32
     a = f32(angle)
@@ -55,7 +57,7 @@ def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture
     direction = direction / np.sqrt(f32(z), dtype=np.float32)
     origin = origin + np.array([0.0, 0.0, altitude], dtype=np.float32)
     return make_camera(origin, direction, (0, 0, 1), image_plane_width=0.75,
-                       plane_of_focus_distance=dof_distance, dof_dispersion=dof_aperture)
+                       plane_of_focus_distance=dof_distance, dof_dispersion=dof_aperture, bounce_mode=bounce_mode)
 
 
 def cli_lights():

@@ -56,13 +56,9 @@ def main():
     sets = {"primary": (o, d), "sphere": (np.ascontiguousarray(so_, np.float32), np.ascontiguousarray(sd, np.float32))}
     costs = {"now": dict(c_round=40, c_tri=80, c_pop=45, c_node=215, c_start=70),
              "lean": dict(c_round=40, c_tri=72, c_pop=20, c_node=97, c_start=77)}[args.costs]
-    policies = [("pops before node (old)", dict(policy=0, max_pops=2, tris_per_round=1, tri_threshold=0)),
-                ("kernel: T|N then pops", dict(policy=4, max_pops=2, tris_per_round=1, tri_threshold=0)),
-                ("kernel pops=3", dict(policy=4, max_pops=3, tris_per_round=1, tri_threshold=0)),
-                ("two groups T,N", dict(policy=2, max_pops=2, tris_per_round=1, tri_threshold=0)),
-                ("two groups N,T", dict(policy=3, max_pops=2, tris_per_round=1, tri_threshold=0)),
-                ("two groups N,T pops=3", dict(policy=3, max_pops=3, tris_per_round=1, tri_threshold=0)),
-                ("either thr=16", dict(policy=1, max_pops=2, tris_per_round=1, tri_threshold=16))]
+    policies = [("kernel: T|N then pops", dict(policy=4, max_pops=2, tris_per_round=1, tri_threshold=0))]
+    for thr in (16, 32, 40, 48, 56):
+        policies.append(("either thr=%d" % thr, dict(policy=1, max_pops=2, tris_per_round=1, tri_threshold=thr)))
     for name, (oo, dd) in sets.items():
         n = len(oo)
         print("== %s: %d rays" % (name, n))

@@ -123,3 +123,26 @@ def test_film_add_restores_accumulators(scene_tiny):
     assert np.array_equal(passes2, 2 * passes) and np.array_equal(rgb2, rgb + rgb)
     with pytest.raises(ValueError):
         film.add(rgb[:10], passes[:10])
+
+
+def test_lambertian_render_matches_oracle(scene_small):
+    """The flagged Lambertian bounce mode: identical ray counts and pass counts, radiance within a
+    few ulp of the oracle's (same paths; bounce terms summed in another order)."""
+    sc = scene_small
+    W, H, S = 96, 64, 3
+    want_rgb, want_p, want_counts = sc.oracle.render(orc.cli_camera(dof_aperture=0.1, dof_distance=4.5, bounce_mode=1),
+                                                     orc.cli_lights(), W, H, None, 0, S, seed=6)
+    film = pta.Film(sc.gpu, W, H)
+    st = film.render(pta.cli_camera(dof_aperture=0.1, dof_distance=4.5, bounce_mode=1), pta.cli_lights(),
+                     [(0, 0, -1, -1, 0, S)], seed=6)
+    rgb, passes = film.read()
+    assert np.array_equal(passes, want_p)
+    assert st.closest_rays == int(want_counts[0]) and st.shadow_rays == int(want_counts[1])
+    err = np.abs(rgb - want_rgb)
+    assert (err <= 1e-5 * np.maximum(np.abs(want_rgb), 1.0)).all(), err.max()
+    film.zero()
+    film.render(pta.cli_camera(dof_aperture=0.1, dof_distance=4.5), pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=6)
+    mirror, _ = film.read()
+    assert not np.array_equal(mirror, rgb)
+    with pytest.raises(RuntimeError):
+        film.render(pta.cli_camera(bounce_mode=7), pta.cli_lights(), [(0, 0, -1, -1, 0, 1)], seed=6)

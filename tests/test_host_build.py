@@ -67,6 +67,12 @@ def test_flat_arrays_encode_the_tree(which, request):
     assert np.array_equal(bits(shade["normal"]), bits(td[:, 15:18])) and np.array_equal(bits(shade["plane"]), bits(td[:, 27]))
     assert np.array_equal(bits(shade["base_n"]), bits(td[:, 18:21]))
     assert np.array_equal(bits(shade["u_n"]), bits(td[:, 21:24])) and np.array_equal(bits(shade["v_n"]), bits(td[:, 24:27]))
+    # d1 = edge01.normalized(), spread over the records' fourth slots (Lambertian bounce frame)
+    e1 = td[:, 9:12]
+    z = e1[:, 0] * e1[:, 0] + (e1[:, 1] * e1[:, 1] + e1[:, 2] * e1[:, 2])
+    d1 = e1 / np.sqrt(z, dtype=np.float32)[:, None]
+    got = np.stack([shade["d1_x"], shade["d1_y"], shade["d1_z"]], axis=1)
+    assert np.array_equal(bits(got), bits(d1.astype(np.float32)))
     # interior nodes carry their children's boxes: compare with the pre-order dump
     interior = dump[dump[:, 0] == 0]
     assert np.array_equal(nodes["axis"], interior[:, 1].astype(np.uint32))   # both are pre-order over interior nodes

@@ -147,3 +147,21 @@ def test_golden_vectors():
     cam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
     rgb, passes, counts = s.render(cam, orc.cli_lights(), 64, 48, None, 0, 2, seed=1)
     assert np.array_equal(bits(rgb), bits(g["render_rgb"])) and counts.tolist() == g["render_counts"].tolist()
+
+
+def test_lambertian_mode_is_a_separate_stream(scene_small):
+    """bounce_mode 1 (integrator.cpp:79-84 without :104): same camera rays and first hits, other
+    bounce directions.  Primary casts are counted alike; the image differs; it is deterministic."""
+    sc = scene_small
+    lights = orc.cli_lights()
+    mirror, pm, cm = sc.oracle.render(orc.cli_camera(), lights, 64, 48, None, 0, 2, seed=4)
+    lam, pl, cl = sc.oracle.render(orc.cli_camera(bounce_mode=1), lights, 64, 48, None, 0, 2, seed=4)
+    lam2, _, cl2 = sc.oracle.render(orc.cli_camera(bounce_mode=1), lights, 64, 48, None, 0, 2, seed=4, threads=3)
+    assert np.array_equal(pm, pl) and np.isfinite(lam).all() and (lam >= 0).all()
+    assert np.array_equal(bits(lam), bits(lam2)) and np.array_equal(cl, cl2)
+    assert not np.array_equal(mirror, lam)
+    # a scattered ray leaves on the side of the geometric normal, so from the floor and the convex
+    # parts of the object it goes on to hit something less often than a mirror ray bounces around;
+    # both modes cast at least the camera rays, at most 11 closest-hit rays per sample
+    n = 64 * 48 * 2
+    assert n <= cl[0] <= 11 * n and n <= cm[0] <= 11 * n
