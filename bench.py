@@ -153,7 +153,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "full path trace (configs[2]): stand-in bumpy icosphere level %d + floor, %d triangles, "
+                "workload": "full path trace (" + ("configs[2]" if (args.level, W, H) == (8, 1920, 1080) else "other scene or size") +
+                            "): stand-in bumpy icosphere level %d + floor, %d triangles, "
                             "3 lights, mirror bounces <= 10, DOF 0.1/4.5, %dx%d, %d spp per step per GPU"
                             % (args.level, host.n, W, H, spp),
                 "triangles": host.n, "width": W, "height": H, "spp_per_step": spp,
