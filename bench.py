@@ -105,6 +105,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     gpu.sync()
+    reduce_film(film_t, dst=0)  # untimed: first use of the collective (communicator, kernels)
+    torch.cuda.synchronize()
     film.zero()
     for c in range(5):
         gpu.kernel_time(c, reset=True)
