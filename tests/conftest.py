@@ -64,6 +64,41 @@ def rays_at_vertices(tris, n, seed=7, radius=3.0):
     return o, d.astype(np.float32)
 
 
+def rays_hostile(tris, n, seed=8):
+    """Rays that stress the arithmetic contract rather than the geometry: one zero direction
+    component (plane-parallel), negative zeros, denormal and huge components, origins far away
+    (beyond the range where the cheaper slab test may be used), origins exactly on vertices and
+    on the floor plane with grazing directions, and non-finite inputs (NaN / infinite origins),
+    for which the reference's comparisons all come out false and the walk still terminates."""
+    rng = np.random.default_rng(seed)
+    o, d = rays_sphere(n, seed=seed + 100)
+    o = o.copy(); d = d.copy()
+    k = np.arange(n)
+    cls = k % 8
+    ax = rng.integers(0, 3, n)
+    m = cls == 0                                   # one component exactly zero
+    d[m, ax[m]] = 0.0
+    m = cls == 1                                   # ... or negative zero
+    d[m, ax[m]] = -0.0
+    m = cls == 2                                   # denormal component
+    d[m, ax[m]] = np.float32(1e-41) * rng.choice([-1.0, 1.0], m.sum()).astype(np.float32)
+    m = cls == 3                                   # far origins, still aimed at the scene
+    scale = rng.choice(np.array([1e3, 1e8, 1e20, 1e31, 3e37], np.float32), m.sum())
+    o[m] = o[m] * scale[:, None]
+    m = cls == 4                                   # origin exactly on a mesh vertex
+    t = tris.reshape(-1, 3, 3)
+    o[m] = t[rng.integers(0, t.shape[0], m.sum()), rng.integers(0, 3, m.sum())]
+    m = cls == 5                                   # in the plane of the lowest vertices, grazing
+    o[m, 2] = tris.reshape(-1, 3)[:, 2].min()
+    d[m, 2] = 0.0
+    m = cls == 6                                   # non-finite origins
+    bad = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), m.sum())
+    o[m, ax[m]] = bad
+    m = cls == 7                                   # huge direction components (not unit length)
+    d[m] = d[m] * rng.choice(np.array([1e-30, 1e-10, 1e10, 1e30], np.float32), m.sum())[:, None]
+    return o.astype(np.float32), d.astype(np.float32)
+
+
 def all_ray_sets(tris, n=20000):
     cam = orc.cli_camera()
     sets = {
@@ -72,6 +107,7 @@ def all_ray_sets(tris, n=20000):
         "inside": rays_inside(n),
         "axis": rays_axis_parallel(n),
         "vertices": rays_at_vertices(tris, n),
+        "hostile": rays_hostile(tris, n),
     }
     return sets
 
