@@ -390,14 +390,14 @@ struct RenderBuffers {
     uint32_t* sh_defer;
     /* counters: [0..11] queue length per depth, [12..23] shadow-ray count per depth,
      * [24..35] shadow rays per depth that need the exact pass, [36] camera samples,
-     * [64..] the queue-region heads of every trace launch of the batch */
+     * [64..] the queue head of every trace launch of the batch */
     uint32_t* cnt;
 };
 #define CNT_QUEUE 0
 #define CNT_SHADOW 12
 #define CNT_DEFER 24
 #define CNT_SAMPLES 36
-#define CNT_CHUNKS 64            /* 8 queue-region heads per (kind, depth): 64 + (kind*12 + depth)*8 */
+#define CNT_CHUNKS 64            /* one queue head per (kind, depth), 32 bytes apart: 64 + (kind*12 + depth)*8 */
 #define CNT_CHUNK(kind, depth) (CNT_CHUNKS + ((kind) * 12 + (depth)) * 8)
 #define CNT_WORDS (CNT_CHUNKS + 3 * 12 * 8)
 
