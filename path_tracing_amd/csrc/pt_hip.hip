@@ -177,9 +177,9 @@ struct TraceArgs {
  * pending leaf, or one interior node, followed by stack pops until it has a leaf or a node
  * again (at most two per round).
  *
- * A round has ONE group of global loads, issued together at its top and consumed after all of
- * them are in flight, so it costs one memory round trip:
- *   - the rays of the lanes being refilled (consumed at the bottom of the round), and
+ * A round consumes ONE group of global loads, all in flight before any is used, so it costs one
+ * memory round trip:
+ *   - the rays of the lanes being refilled, and
  *   - one 64-byte record per lane: the lane's next triangle (48 bytes used) or its interior
  *     node, fetched through one per-lane address so that the same four load instructions
  *     serve both kinds of lane.
@@ -228,11 +228,110 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     bool first_chunk = true;              /* wave-uniform */
     const bool scene_tame = root_is_tame(sc.root);
 
+    /* The loop is software-pipelined: the loads a round consumes are issued during the round
+     * before it -- a lane's next record as soon as its pops are done, the rays of refilled
+     * lanes once the retiring lanes are known -- and the result stores, the queue bookkeeping
+     * and the start of new rays run while they are in flight. */
+    float4 q0, q1, q2, q3;                    /* the lane's record for this round; meaningful where rec_* says so */
+    bool rec_tri = false, rec_node = false;   /* what was loaded for this lane: a triangle / an interior node */
+    bool starting = false;                    /* this lane's registers are receiving a new ray */
+    uint32_t new_ray = 0;
+
     while (true) {
-        /* ---- refill idle lanes ---- */
+        /* The round's single wait: every register a load of the previous round may have targeted
+         * is named as an input of an empty statement, so those loads are complete from here on
+         * along every control path and nothing below waits on global memory again. */
+        asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                           "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist));
+
+        /* ---- start the refilled lanes (they take their first record with everyone else below) ---- */
+        bool defer = false;
+        if (starting) {
+            /* Every hit has v <= 1, so with dist >= 1 the reference's test `v > dist` fails for any
+             * hit and the answer is hit/no-hit.  Nearer lights need the closest hit's v: those rays
+             * are queued for the exact pass. */
+            if (MODE == TRACE_SHADOW_ANY && !(dist >= 1.0f)) defer = true;
+            else {
+                ray_set_recip(L.r);
+                lane_start(L, sc.root_ref, sc.root, scene_tame);
+                ray = (int32_t)new_ray;
+            }
+        }
+        if (MODE == TRACE_SHADOW_ANY) {
+            const uint64_t dm = __ballot(defer);
+            if (dm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.defer_count, (uint32_t)__popcll(dm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (defer) a.defer_list[base + (uint32_t)__popcll(dm & lt_mask)] = new_ray;
+            }
+        }
+        const bool active = ray >= 0;
+
+        /* ---- one step per lane that has its record ---- */
+        if (rec_tri) {
+            TriData tr;
+            tr.p0x = q0.x; tr.p0y = q0.y; tr.p0z = q0.z;
+            tr.e1x = q0.w; tr.e1y = q1.x; tr.e1z = q1.y;
+            tr.e2x = q1.z; tr.e2y = q1.w; tr.e2z = q2.x;
+            tr.mesh_index = __float_as_uint(q2.y); tr.leaf_remaining = __float_as_uint(q2.w);
+            lane_tri<ANY>(L, tr);
+        }
+        {
+            NodeData nd;
+            nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
+            nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
+            nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
+            if (__any(rec_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
+                if (rec_node) lane_node<ANY, false>(L, nd, st);
+            } else {
+                if (rec_node) lane_node<ANY, true>(L, nd, st);
+            }
+        }
+
+        /* ---- lanes left with neither a leaf nor a node take their next one from the stack ---- */
+        if (active && L.cur == PT_REF_NONE && L.sp > 0) {
+            lane_pop<ANY>(L, st);
+            if (L.cur == PT_REF_NONE && L.sp > 0) lane_pop<ANY>(L, st);
+        }
+        /* ---- next round's records (one load site: a second one for the lanes that know their
+         * record before the pops would make the compiler wait for the first, since both target
+         * the same registers) ---- */
+        rec_tri = active && lane_has_leaf(L);
+        rec_node = active && lane_has_node(L);
+        if (rec_tri || rec_node) {
+            const float4* rec = rec_tri ? sc.tris + (size_t)lane_leaf_pos(L) * 3 : sc.nodes + (size_t)L.cur * 4;
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+            if (rec_node) q3 = rec[3];
+        }
+
+        /* ---- retire finished rays ---- */
+        if (active && lane_finished(L)) {
+            const uint32_t i = (uint32_t)ray;
+            if (CLOSEST_OUT) {
+                if (MODE == TRACE_CLOSEST_FLAT) {
+                    float4 h;
+                    h.x = __uint_as_float(L.found ? L.best.tri : 0xffffffffu);
+                    h.y = L.found ? L.best.t : 0.0f; h.z = L.found ? L.best.u : 0.0f; h.w = L.found ? L.best.v : 0.0f;
+                    a.out_hit[i] = h;
+                } else {
+                    a.out_idx[i] = L.found ? (int32_t)L.best.mesh : -1;
+                    a.out_t[i] = L.found ? L.best.t : 0.0f;
+                    a.out_u[i] = L.found ? L.best.u : 0.0f;
+                    a.out_v[i] = L.found ? L.best.v : 0.0f;
+                }
+            } else if (MODE == TRACE_SHADOW_ANY) {
+                a.vis[i] = L.found ? 0 : 1;
+            } else {
+                a.vis[i] = (!L.found || L.best.v > dist) ? 1 : 0;
+            }
+            ray = -1;
+        }
+
+        /* ---- refill idle lanes: their rays are loaded now and started at the top of the next round ---- */
         const uint64_t idle = __ballot(ray < 0);
-        bool starting = false;
-        uint32_t new_ray = 0;
+        starting = false;
         if (idle) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
@@ -260,101 +359,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             }
             if (exhausted && idle == ~0ull) break;
         }
-        /* ---- this round's loads ----
-         * The record of every lane that holds a ray: its next triangle, or its interior node. */
-        const bool active = ray >= 0;
-        const bool do_tri = active && lane_has_leaf(L);
-        const bool do_node = active && !do_tri && lane_has_node(L);
-        float4 q0, q1, q2, q3;   /* meaningful only in lanes with do_tri / do_node */
-        if (do_tri || do_node) {
-            const float4* rec = do_tri ? sc.tris + (size_t)lane_leaf_pos(L) * 3 : sc.nodes + (size_t)L.cur * 4;
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
-            if (do_node) q3 = rec[3];
-        }
-        /* The rays of the lanes being refilled.  A starting lane is idle, so its ray registers
-         * are dead: the new ray is loaded straight into them. */
+        /* A starting lane is idle, so its ray registers are dead: the new ray is loaded straight
+         * into them. */
         if (starting) {
             if (MODE == TRACE_SHADOW_EXACT) new_ray = a.defer_list[new_ray];
             if (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_EXACT) dist = a.dist[new_ray];
             L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
             L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
-        }
-        /* The round's single wait: every register a load above may have targeted is named as an
-         * input of an empty statement, so the loads are complete from here on along every
-         * control path, and nothing below or in the next round waits on global memory again. */
-        asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
-                           "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
-        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist));
-
-        /* ---- one step per lane ---- */
-        if (do_tri) {
-            TriData tr;
-            tr.p0x = q0.x; tr.p0y = q0.y; tr.p0z = q0.z;
-            tr.e1x = q0.w; tr.e1y = q1.x; tr.e1z = q1.y;
-            tr.e2x = q1.z; tr.e2y = q1.w; tr.e2z = q2.x;
-            tr.mesh_index = __float_as_uint(q2.y); tr.leaf_remaining = __float_as_uint(q2.w);
-            lane_tri<ANY>(L, tr);
-        }
-        {
-            NodeData nd;
-            nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
-            nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
-            nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
-            if (__any(do_node && !L.tame)) {   /* wave-uniform: some lane needs the NaN-exact box test */
-                if (do_node) lane_node<ANY, false>(L, nd, st);
-            } else {
-                if (do_node) lane_node<ANY, true>(L, nd, st);
-            }
-        }
-        /* ---- lanes left with neither a leaf nor a node take their next one from the stack ---- */
-        if (active && L.cur == PT_REF_NONE && L.sp > 0) {
-            lane_pop<ANY>(L, st);
-            if (L.cur == PT_REF_NONE && L.sp > 0) lane_pop<ANY>(L, st);
-        }
-        /* ---- retire finished rays ---- */
-        if (active && lane_finished(L)) {
-            const uint32_t i = (uint32_t)ray;
-            if (CLOSEST_OUT) {
-                if (MODE == TRACE_CLOSEST_FLAT) {
-                    float4 h;
-                    h.x = __uint_as_float(L.found ? L.best.tri : 0xffffffffu);
-                    h.y = L.found ? L.best.t : 0.0f; h.z = L.found ? L.best.u : 0.0f; h.w = L.found ? L.best.v : 0.0f;
-                    a.out_hit[i] = h;
-                } else {
-                    a.out_idx[i] = L.found ? (int32_t)L.best.mesh : -1;
-                    a.out_t[i] = L.found ? L.best.t : 0.0f;
-                    a.out_u[i] = L.found ? L.best.u : 0.0f;
-                    a.out_v[i] = L.found ? L.best.v : 0.0f;
-                }
-            } else if (MODE == TRACE_SHADOW_ANY) {
-                a.vis[i] = L.found ? 0 : 1;
-            } else {
-                a.vis[i] = (!L.found || L.best.v > dist) ? 1 : 0;
-            }
-            ray = -1;
-        }
-
-        /* ---- start the refilled lanes (their loads were issued at the top of the round) ---- */
-        bool defer = false;
-        if (starting) {
-            /* Every hit has v <= 1, so with dist >= 1 the reference's test `v > dist` fails for any
-             * hit and the answer is hit/no-hit.  Nearer lights need the closest hit's v: those rays
-             * are queued for the exact pass. */
-            if (MODE == TRACE_SHADOW_ANY && !(dist >= 1.0f)) defer = true;
-            else {
-                ray_set_recip(L.r);
-                lane_start(L, sc.root_ref, sc.root, scene_tame);
-                ray = (int32_t)new_ray;
-            }
-        }
-        if (MODE == TRACE_SHADOW_ANY) {
-            const uint64_t dm = __ballot(defer);
-            if (dm) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.defer_count, (uint32_t)__popcll(dm));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (defer) a.defer_list[base + (uint32_t)__popcll(dm & lt_mask)] = new_ray;
-            }
         }
     }
 }
