@@ -30,7 +30,9 @@ def counter_sum(root, counter, kernel):
 
 def main():
     root = sys.argv[1]
-    line = json.loads(open(os.path.join(root, "bench_line_under_profiler.json")).read().strip().splitlines()[-1])
+    # the PMC passes run `bench.py --steps 2 --warmup 1`; their own bench line gives the ray counts
+    name = "bench_line_under_pmc.json" if os.path.exists(os.path.join(root, "bench_line_under_pmc.json")) else "bench_line_under_profiler.json"
+    line = json.loads(open(os.path.join(root, name)).read().strip().splitlines()[-1])
     steps_total = line["steps"] + line["warmup"]
     out = {"source": os.path.basename(root.rstrip("/")), "bench_line": {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}}
     for name, kernel, key in (("closest", "k_trace<1>", "closest_rays"), ("shadow", "k_trace<2>", "shadow_rays")):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box from the repo root):
-#   1. kernel trace + stats of the default bench.py command (GPU part only);
+#   1. kernel trace + stats of the default bench.py command (`python3 bench.py`, the line the driver records);
 #   2. PMC passes of the same command, one counter group per run (never combined with tracing
 #      beyond --kernel-trace): HBM-side traffic (FETCH_SIZE, WRITE_SIZE), L2 hit rate, SQ busy/
 #      wait/VALU counters, L1 counters;
@@ -12,7 +12,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -o bench -- $BENCH > $OUT/bench_stats.log 2>&1 || { echo "kernel trace failed"; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -o bench -- python3 bench.py > $OUT/bench_stats.log 2>&1 || { echo "kernel trace failed"; exit 1; }
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
@@ -25,4 +25,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
 done
 python3 scripts/rocpd_summary.py $OUT > $OUT/summary.txt
 grep -h '^{' $OUT/bench_stats.log > $OUT/bench_line_under_profiler.json
+grep -h '^{' $OUT/pmc1.log > $OUT/bench_line_under_pmc.json
 echo done > $OUT/finished.txt
