@@ -192,6 +192,14 @@ int  pt_film_zero(pt_film* f);                         /* Canvas::zero, canvas.c
 float* pt_film_device_ptr(pt_film* f);
 /* Copies out Canvas::pixels (W*H*3) and Canvas::per_pixel_passes (W*H); waits for rendering. */
 int  pt_film_read(pt_film* f, float* rgb_sum, int32_t* per_pixel_passes);
+/* Sums n films of the same size, one per GPU (films[0] may be the only one), and copies out the
+ * total as pt_film_read does: RenderEngine::rebuild_master_canvas (integrator.cpp:469-487),
+ * i.e. Canvas::add_from over all workers (canvas.cpp:47-52).  For n > 1 the sum is ONE RCCL
+ * sum-reduce of W*H*4 floats over xGMI to films[0]'s GPU (communicators for the device set are
+ * created on first use and kept); the films themselves are left unchanged.  RCCL is loaded on
+ * first use, so programs that never call this do not depend on it.  All films must belong to
+ * different GPUs; the calling thread must be the only one using them during the call. */
+int  pt_films_reduce(pt_film* const* films, int n, float* rgb_sum, int32_t* per_pixel_passes);
 /* Adds host accumulators of the same size into the film (Canvas::add_from with a host Canvas,
  * canvas.cpp:47-52): how a render resumes from accumulators saved earlier. */
 int  pt_film_add(pt_film* f, const float* rgb_sum, const int32_t* per_pixel_passes);

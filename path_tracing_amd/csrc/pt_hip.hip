@@ -23,6 +23,8 @@
  * Build: hipcc -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950
  */
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -1170,6 +1172,98 @@ int pt_film_read(pt_film* f, float* rgb_sum, int32_t* passes) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rgb_sum, d_rgb.p, n * 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(passes, d_p.p, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+/* RCCL entry points, resolved on first use (see pt_films_reduce in pt_hip.h). */
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<int> devices;        /* device set of the cached communicators */
+    std::vector<ncclComm_t> comms;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return PT_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    if (!lib) return fail(PT_ERR_DEVICE, std::string("cannot load RCCL: ") + dlerror());
+    RcclApi r;
+    r.lib = lib;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(lib, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.Reduce = (decltype(r.Reduce))dlsym(lib, "ncclReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.Reduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        dlclose(lib);
+        return fail(PT_ERR_DEVICE, "RCCL library lacks an expected entry point");
+    }
+    g_rccl = r;
+    return PT_OK;
+}
+
+#define RCCL_TRY(expr)                                                                               \
+    do {                                                                                             \
+        ncclResult_t r_ = (expr);                                                                    \
+        if (r_ != ncclSuccess) return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+int pt_films_reduce(pt_film* const* films, int n, float* rgb_sum, int32_t* passes) {
+    if (!films || n < 1 || !rgb_sum || !passes) return fail(PT_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; i++) {
+        if (!films[i]) return fail(PT_ERR_INVALID, "null film");
+        if (films[i]->width != films[0]->width || films[i]->height != films[0]->height) return fail(PT_ERR_INVALID, "films differ in size");
+        for (int j = 0; j < i; j++)
+            if (films[j]->scene->device == films[i]->scene->device) return fail(PT_ERR_INVALID, "two films on one GPU");
+    }
+    const char* force = getenv("PT_FILMS_REDUCE");   /* "rccl": use the collective even for one film */
+    if (n == 1 && !(force && strcmp(force, "rccl") == 0)) return pt_film_read(films[0], rgb_sum, passes);
+    int rc = rccl_load();
+    if (rc) return rc;
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; i++) devs[(size_t)i] = films[i]->scene->device;
+    if (g_rccl.devices != devs) {
+        for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+        g_rccl.comms.assign((size_t)n, nullptr);
+        g_rccl.devices.clear();
+        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n, devs.data()));
+        g_rccl.devices = devs;
+    }
+    pt_film* root = films[0];
+    const size_t npx = (size_t)root->width * root->height;
+    rc = set_device(root->scene);
+    if (rc) return rc;
+    DevBuf d_sum, d_rgb, d_p;
+    rc = d_sum.alloc(npx * 16); if (rc) return rc;
+    rc = d_rgb.alloc(npx * 12); if (rc) return rc;
+    rc = d_p.alloc(npx * 4); if (rc) return rc;
+    /* every film's stream is ordered after its rendering, so the reduce reads finished films */
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(films[i]->scene->device));
+        RCCL_TRY(g_rccl.Reduce(films[i]->d_film, i == 0 ? d_sum.p : (void*)films[i]->d_film, npx * 4, ncclFloat, ncclSum, 0,
+                               g_rccl.comms[(size_t)i], films[i]->scene->stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    for (int i = n - 1; i >= 0; i--) {
+        HIP_TRY(hipSetDevice(films[i]->scene->device));
+        HIP_TRY(hipStreamSynchronize(films[i]->scene->stream));
+    }
+    pt_scene* s = root->scene;   /* the current device is the root's again */
+    hipLaunchKernelGGL(k_film_split, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s->stream, (const float4*)d_sum.p, npx, (float*)d_rgb.p, (int32_t*)d_p.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_sum, d_rgb.p, npx * 12, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(passes, d_p.p, npx * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PT_OK;
 }

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -544,6 +545,32 @@ void RenderEngine::kill_workers() {
 int RenderEngine::rebuild_master_canvas() {
     master_canvas->zero();
     int total_passes = 0;
+    /* Several GPUs: one RCCL sum-reduce of the films on the device side (pt_films_reduce), the
+     * workers' own canvases are then not refreshed.  PT_FILMS_REDUCE=host keeps the host-side
+     * sum below, which is also the fallback if the collective cannot be set up. */
+    const char* how = getenv("PT_FILMS_REDUCE");
+    const bool want_rccl = how ? strcmp(how, "rccl") == 0 : workers.size() > 1;
+    if (want_rccl && !workers.empty()) {
+        vector<pt_film*> films;
+        for (auto worker : workers) {
+            pthread_mutex_lock(&worker->integrator_lock);
+            if (worker->integrator->film) films.push_back(worker->integrator->film);
+            total_passes += worker->integrator->passes;
+        }
+        int rc = -1;
+        if (films.size() == workers.size()) {
+            vector<float> rgb((size_t)master_canvas->size * 3);
+            rc = pt_films_reduce(films.data(), (int)films.size(), rgb.data(), master_canvas->per_pixel_passes);
+            if (rc == PT_OK)
+                for (int i = 0; i < master_canvas->size; i++)
+                    master_canvas->pixels[i] = Vec(rgb[3 * (size_t)i], rgb[3 * (size_t)i + 1], rgb[3 * (size_t)i + 2]);
+        }
+        for (auto worker : workers) pthread_mutex_unlock(&worker->integrator_lock);
+        if (rc == PT_OK) return total_passes;
+        cerr << "rebuild_master_canvas: device-side reduce failed (" << pt_last_error() << "), summing on the host" << endl;
+        master_canvas->zero();
+        total_passes = 0;
+    }
     for (auto worker : workers) {
         pthread_mutex_lock(&worker->integrator_lock);
         worker->integrator->download();

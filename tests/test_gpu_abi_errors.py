@@ -105,3 +105,23 @@ def test_zero_then_reuse(scene_small):
     film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 2)], seed=1)
     b, pb = film.read()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(pa, pb)
+
+
+def test_films_reduce_arguments(scene_tiny):
+    import ctypes as C
+    from path_tracing_amd import native
+    L = native.hip_lib()
+    gpu = pta.GpuScene(scene_tiny.host, 0)
+    a, b = pta.Film(gpu, 32, 16), pta.Film(gpu, 32, 16)
+    a.render(pta.cli_camera(), pta.cli_lights(), [(0, 0, -1, -1, 0, 2)], seed=1)
+    rgb = np.zeros((16, 32, 3), np.float32)
+    passes = np.zeros((16, 32), np.int32)
+    one = (C.c_void_p * 1)(a.h)
+    assert L.pt_films_reduce(one, 1, rgb.ctypes.data, passes.ctypes.data) == 0
+    want_rgb, want_p = a.read()
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(passes, want_p)
+    assert L.pt_films_reduce(one, 0, rgb.ctypes.data, passes.ctypes.data) == -1
+    assert L.pt_films_reduce(one, 1, None, passes.ctypes.data) == -1
+    two = (C.c_void_p * 2)(a.h, b.h)
+    assert L.pt_films_reduce(two, 2, rgb.ctypes.data, passes.ctypes.data) == -1
+    assert b"one GPU" in L.pt_last_error()

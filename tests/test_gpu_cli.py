@@ -114,3 +114,20 @@ def test_checkpoint_and_resume(tmp_path, scene_small):
     res = subprocess.run(base[:2] + ["--width", "80", "--height", "60", "--samples", "1", "--resume", acc4,
                                      "--output", str(tmp_path / "x.png")], capture_output=True, text=True, timeout=300)
     assert res.returncode == 1 and "Couldn't resume from" in res.stdout
+
+
+def test_device_side_film_reduce(tmp_path, scene_small):
+    """RenderEngine::rebuild_master_canvas through pt_films_reduce: with PT_FILMS_REDUCE=rccl the
+    films are summed by an RCCL reduce on the device side even on one GPU (a one-rank
+    communicator); the picture must be the one the plain read-back gives."""
+    stl = str(tmp_path / "standin.stl")
+    pta.meshgen.write_stl(stl, scene_small.tris)
+    outs = []
+    for how in ("host", "rccl"):
+        out = str(tmp_path / (how + ".png"))
+        cmd = [CLI, stl, "--output", out, "--width", "200", "--height", "120", "--samples", "3", "--seed", "2"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, PT_FILMS_REDUCE=how))
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert "reduce failed" not in res.stderr, res.stderr
+        outs.append(_read_png(out))
+    assert np.array_equal(outs[0], outs[1])
