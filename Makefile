@@ -49,7 +49,11 @@ $(PKG)/bin/animate: $(PKG)/host/animate.cpp include/pt_render.h $(LIBDIR)/libpt_
 	$(CXX) $(HOSTFLAGS) -o $@ $(PKG)/host/animate.cpp -L$(LIBDIR) -lpt_render -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,$(ROCM)/lib
 
 # Lane-level emulation of the device traversal on the CPU (tests only).
-native-tests: tests/native/_build/libtraverse_emul.so tests/native/_build/libpt_hip_smallstack.so
+native-tests: tests/native/_build/libtraverse_emul.so tests/native/_build/libpt_hip_smallstack.so tests/native/_build/api_check
+# Exercises the C++ API directly (tests/test_gpu_cpp_api.py).
+tests/native/_build/api_check: tests/native/api_check.cpp include/pt_render.h $(LIBDIR)/libpt_render.so
+	mkdir -p tests/native/_build
+	$(CXX) $(HOSTFLAGS) -o $@ tests/native/api_check.cpp -L$(LIBDIR) -lpt_render -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -Wl,-rpath-link,$(ROCM)/lib
 # The same HIP library with only 4 stack entries per lane in LDS: nearly every ray then uses the
 # spill path to HBM, which the regular build needs for < 1 % of rays (tests/test_gpu_spill.py).
 tests/native/_build/libpt_hip_smallstack.so: $(HIP_SRCS) $(HIP_HDRS)
