@@ -39,7 +39,7 @@ extern "C" {
 #define PT_MAX_TRIANGLES   ((1u << 26) - 64u)
 #define PT_MAX_TREE_DEPTH  20      /* interior levels above any leaf; reference caps at 19 (kdtree.cpp:13) */
 #define PT_MAX_LIGHTS      16
-#define PT_MAX_RAYS_PER_CALL 0xf0000000ull  /* one ray-cast call; the 32-bit queue head needs headroom above it */
+#define PT_MAX_RAYS_PER_CALL 0xf0000000ull  /* rays of one ray-cast call (ray indices are 32-bit) */
 
 /* One interior node of the reference's tree (kdTreeNode, kdtree.h:19-36), holding the
  * AABBs of BOTH children so a visit needs one 64-byte load.  The node's own box lives in
@@ -89,7 +89,8 @@ int  pt_device_count(int* n);
 /* Uploads the flattened tree; immutable afterwards.  Replaces the device-less
  * `new kdTree(mesh)` result that Scene holds (integrator.cpp:30).  The arrays are checked
  * (child references in range, depth <= PT_MAX_TREE_DEPTH, leaf ranges inside the triangle
- * array) so that a malformed tree is rejected here instead of faulting a kernel. */
+ * array, leaf_remaining counting down to each leaf's end) so that a malformed tree is rejected
+ * here instead of faulting a kernel. */
 int  pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out);
 void pt_scene_destroy(pt_scene* s);
 
