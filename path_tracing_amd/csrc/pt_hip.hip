@@ -620,6 +620,10 @@ __global__ void k_film_add(float4* film, size_t n, const float* rgb, const int32
 
 struct TimedLaunch { int cls; hipEvent_t a, b; };
 
+/* Where a kernel goes: the stream, and the stack spill area that the trace launches of that
+ * stream share (launches on one stream run one after another). */
+struct LaunchCtx { hipStream_t stream; uint32_t* spill; };
+
 struct pt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -631,6 +635,11 @@ struct pt_scene {
     uint64_t n_tris = 0;
     uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, [8..15] and [16..23] queue heads */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
+    /* second render lane (see pt_render_passes): its own stream and spill area, made on first use */
+    hipStream_t stream2 = nullptr;
+    uint32_t* d_spill2 = nullptr;
+    size_t spill_bytes = 0;
+    hipEvent_t ev_order = nullptr;
     uint32_t* d_defer = nullptr; /* deferred shadow rays of pt_raycast_shadow_dev */
     uint64_t defer_cap = 0;
     int grid_closest = 0, grid_any = 0; /* resident blocks of the persistent trace kernels */
@@ -658,6 +667,7 @@ static hipEvent_t get_event(pt_scene* s) {
 static int resolve_timing(pt_scene* s) {
     if (s->pending.empty()) return PT_OK;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));
     for (auto& t : s->pending) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { s->ms[t.cls] += ms; s->launches[t.cls]++; }
@@ -669,15 +679,15 @@ static int resolve_timing(pt_scene* s) {
 }
 
 struct ScopedTimer {
-    pt_scene* s; int cls; hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(pt_scene* s_, int cls_) : s(s_), cls(cls_) {
+    pt_scene* s; int cls; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(pt_scene* s_, int cls_, hipStream_t stream_ = nullptr) : s(s_), cls(cls_), stream(stream_ ? stream_ : s_->stream) {
         if (!s->timing) return;
         a = get_event(s); b = get_event(s);
-        if (a && b) (void)hipEventRecord(a, s->stream);
+        if (a && b) (void)hipEventRecord(a, stream);
     }
     ~ScopedTimer() {
         if (!s->timing || !a || !b) return;
-        (void)hipEventRecord(b, s->stream);
+        (void)hipEventRecord(b, stream);
         s->pending.push_back({cls, a, b});
     }
 };
@@ -782,6 +792,7 @@ void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     for (auto& t : s->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : s->free_events) (void)hipEventDestroy(e);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -789,7 +800,10 @@ void pt_scene_destroy(pt_scene* s) {
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_small) (void)hipFree(s->d_small);
     if (s->d_spill) (void)hipFree(s->d_spill);
+    if (s->d_spill2) (void)hipFree(s->d_spill2);
     if (s->d_defer) (void)hipFree(s->d_defer);
+    if (s->ev_order) (void)hipEventDestroy(s->ev_order);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -799,6 +813,7 @@ int pt_scene_sync(pt_scene* s) {
     int rc = set_device(s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->stream2) HIP_TRY(hipStreamSynchronize(s->stream2));
     return PT_OK;
 }
 
@@ -821,12 +836,13 @@ int pt_scene_kernel_time(pt_scene* s, int cls, int reset, double* ms, uint64_t* 
 static int trace_grid(const pt_scene* s, bool anyhit) { return anyhit ? s->grid_any : s->grid_closest; }
 
 template <int MODE>
-static int launch_trace(pt_scene* s, TraceArgs a) {
-    if (s->pending.size() > 8192) { int rc = resolve_timing(s); if (rc) return rc; }
-    a.spill = s->d_spill;
+static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr) {
+    if (!ctx && s->pending.size() > 8192) { int rc = resolve_timing(s); if (rc) return rc; }
+    const LaunchCtx here = ctx ? *ctx : LaunchCtx{s->stream, s->d_spill};
+    a.spill = here.spill;
     if (a.count_mul == 0) a.count_mul = 1;
-    ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW);
-    hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY)), dim3(TRACE_BLOCK), 0, s->stream, s->d, a);
+    ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW, here.stream);
+    hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY)), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -844,7 +860,16 @@ static int init_trace_launch(pt_scene* s) {
     s->grid_any = s->num_cus * per_cu_a;
     size_t threads = (size_t)std::max(s->grid_closest, s->grid_any) * TRACE_BLOCK;
     size_t words = threads * (size_t)(STACK_MAX_CLOSEST - STACK_LDS);
-    HIP_TRY(hipMalloc((void**)&s->d_spill, words * sizeof(uint32_t)));
+    s->spill_bytes = words * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void**)&s->d_spill, s->spill_bytes));
+    return PT_OK;
+}
+
+/* The second render lane's stream, spill area and ordering event, made on first use. */
+static int ensure_second_lane(pt_scene* s) {
+    if (!s->stream2) HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+    if (!s->d_spill2) HIP_TRY(hipMalloc((void**)&s->d_spill2, s->spill_bytes));
+    if (!s->ev_order) HIP_TRY(hipEventCreateWithFlags(&s->ev_order, hipEventDisableTiming));
     return PT_OK;
 }
 
@@ -965,12 +990,9 @@ int pt_raycast_shadow(pt_scene* s, uint64_t n, const float* ox, const float* oy,
 
 /* -------------------------------------------------------------------- film */
 
-struct pt_film {
-    pt_scene* scene = nullptr;
-    int width = 0, height = 0;
-    float4* d_film = nullptr;
-    bool owns = false;
-    /* render scratch, allocated on first use */
+/* One render lane: the scratch of one batch in flight, and the host-side staging that the
+ * batch's asynchronous copies read from or write to until the lane's stream has been waited for. */
+struct RenderLane {
     size_t cap_paths = 0;
     uint32_t cap_lights = 0;
     std::vector<void*> allocs;
@@ -979,6 +1001,22 @@ struct pt_film {
     SubPass* d_sub = nullptr;
     uint32_t* d_groups = nullptr; /* group_entry[cap] then group_off[cap+1] */
     size_t cap_sub = 0;
+    uint32_t* h_cnt = nullptr;    /* pinned: the batch's counters */
+    hipEvent_t film_done = nullptr;
+    std::vector<SubPass> h_sub;
+    std::vector<uint32_t> h_entry, h_off;
+    bool in_flight = false;
+    uint32_t flight_lights = 0;
+};
+
+#define RENDER_LANES 2
+
+struct pt_film {
+    pt_scene* scene = nullptr;
+    int width = 0, height = 0;
+    float4* d_film = nullptr;
+    bool owns = false;
+    RenderLane lane[RENDER_LANES]; /* render scratch, allocated on first use */
 };
 
 static size_t batch_paths_limit() {
@@ -989,15 +1027,33 @@ static size_t batch_paths_limit() {
     return v;
 }
 
-static void film_free_scratch(pt_film* f) {
+/* Number of batches in flight at once: 1 unless PT_RENDER_LANES=2.  Two lanes render 2-3 % more
+ * rays per second on a full 1080p step (the lanes fill each other's launch tails), but every
+ * kernel then shares the GPU with the other lane's, so per-kernel event times
+ * (pt_scene_kernel_time, a profiler's kernel trace) stop meaning busy time; one lane is the
+ * default for that reason. */
+static int render_lanes() {
+    const char* e = getenv("PT_RENDER_LANES");
+    return (e && atoi(e) >= 2) ? RENDER_LANES : 1;
+}
+
+static void lane_free_scratch(RenderLane* f) {
     for (void* p : f->allocs) (void)hipFree(p);
     f->allocs.clear();
     f->cap_paths = 0; f->cap_lights = 0; f->cap_sub = 0;
     f->d_lights = nullptr; f->d_sub = nullptr; f->d_groups = nullptr;
 }
 
+static void film_free_scratch(pt_film* f) {
+    for (RenderLane& ln : f->lane) {
+        lane_free_scratch(&ln);
+        if (ln.h_cnt) { (void)hipHostFree(ln.h_cnt); ln.h_cnt = nullptr; }
+        if (ln.film_done) { (void)hipEventDestroy(ln.film_done); ln.film_done = nullptr; }
+    }
+}
+
 template <class T>
-static int film_alloc(pt_film* f, T** out, size_t count) {
+static int film_alloc(RenderLane* f, T** out, size_t count) {
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
     f->allocs.push_back(p);
@@ -1005,11 +1061,13 @@ static int film_alloc(pt_film* f, T** out, size_t count) {
     return PT_OK;
 }
 
-static int film_ensure_scratch(pt_film* f, size_t paths, uint32_t n_lights, size_t n_sub) {
+/* The lane must be idle (its stream waited for) when this is called. */
+static int lane_ensure_scratch(RenderLane* f, size_t paths, uint32_t n_lights, size_t n_sub) {
+    if (!f->h_cnt) HIP_TRY(hipHostMalloc((void**)&f->h_cnt, CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    if (!f->film_done) HIP_TRY(hipEventCreateWithFlags(&f->film_done, hipEventDisableTiming));
     uint32_t L = std::max<uint32_t>(n_lights, 1);
     if (paths <= f->cap_paths && L <= f->cap_lights && n_sub <= f->cap_sub) return PT_OK;
-    HIP_TRY(hipStreamSynchronize(f->scene->stream));
-    film_free_scratch(f);
+    lane_free_scratch(f);
     size_t P = paths, S = paths * L, G = std::max<size_t>(n_sub, 16);
     int rc = 0;
     RenderBuffers& b = f->rb;
@@ -1031,7 +1089,7 @@ static int film_ensure_scratch(pt_film* f, size_t paths, uint32_t n_lights, size
     if (!rc) rc = film_alloc(f, &f->d_lights, (size_t)PT_MAX_LIGHTS);
     if (!rc) rc = film_alloc(f, &f->d_sub, G);
     if (!rc) rc = film_alloc(f, &f->d_groups, 2 * G + 2);
-    if (rc) { film_free_scratch(f); return rc; }
+    if (rc) { lane_free_scratch(f); return rc; }
     f->cap_paths = P; f->cap_lights = L; f->cap_sub = G;
     return PT_OK;
 }
@@ -1048,25 +1106,31 @@ static void fill_cam(CamParams& c, const pt_camera* cam, int width, int height) 
     c.bounce_mode = cam->bounce_mode;
 }
 
-/* Renders one batch (already clamped, grouped and numbered) with no host round trip. */
-static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, const std::vector<SubPass>& sub,
-                        uint32_t n_paths, uint64_t seed, uint64_t counts[3]) {
+/* Queues one batch (already clamped, grouped and numbered, in ln.h_sub) on the lane's stream
+ * with no host round trip.  The film kernel waits for `after` (the previous batch's film
+ * kernel, which may be on the other lane) so that batches reach the film in order; the batch's
+ * counters land in ln.h_cnt once the stream has been waited for. */
+static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const CamParams& cam, uint32_t n_lights,
+                        uint32_t n_paths, uint64_t seed, hipEvent_t after) {
     pt_scene* s = f->scene;
-    RenderBuffers& b = f->rb;
+    RenderBuffers& b = ln.rb;
+    hipStream_t st = ctx.stream;
+    const std::vector<SubPass>& sub = ln.h_sub;
     /* rectangle groups for the film kernel */
-    std::vector<uint32_t> g_entry, g_off;
+    std::vector<uint32_t>&g_entry = ln.h_entry, &g_off = ln.h_off;
+    g_entry.clear(); g_off.clear();
     uint32_t total = 0;
     for (uint32_t e = 0; e < sub.size(); e++)
         if (sub[e].group_first == e) { g_entry.push_back(e); g_off.push_back(total); total += sub[e].padded; }
     g_off.push_back(total);
     uint32_t n_groups = (uint32_t)g_entry.size();
-    HIP_TRY(hipMemcpyAsync(f->d_sub, sub.data(), sub.size() * sizeof(SubPass), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(f->d_groups, g_entry.data(), n_groups * 4, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(f->d_groups + f->cap_sub, g_off.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, s->stream));
+    HIP_TRY(hipMemcpyAsync(ln.d_sub, sub.data(), sub.size() * sizeof(SubPass), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ln.d_groups, g_entry.data(), n_groups * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ln.d_groups + ln.cap_sub, g_off.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, st));
     {
-        ScopedTimer tm(s, PT_KERNEL_GENERATE);
-        hipLaunchKernelGGL(k_generate, dim3((n_paths + STREAM_BLOCK - 1) / STREAM_BLOCK), dim3(STREAM_BLOCK), 0, s->stream, cam, f->d_sub, (uint32_t)sub.size(),
+        ScopedTimer tm(s, PT_KERNEL_GENERATE, st);
+        hipLaunchKernelGGL(k_generate, dim3((n_paths + STREAM_BLOCK - 1) / STREAM_BLOCK), dim3(STREAM_BLOCK), 0, st, cam, ln.d_sub, (uint32_t)sub.size(),
                            n_paths, seed, b);
         HIP_TRY(hipGetLastError());
     }
@@ -1079,11 +1143,11 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
         a.d_count = b.cnt + CNT_QUEUE + depth;
         a.d_next_chunk = b.cnt + CNT_CHUNK(0, depth);
         a.out_hit = b.hit;
-        int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a);
+        int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a, &ctx);
         if (rc) return rc;
         {
-            ScopedTimer tm(s, PT_KERNEL_SHADE);
-            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, s->stream, s->d, cam, f->d_lights, n_lights, depth,
+            ScopedTimer tm(s, PT_KERNEL_SHADE, st);
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, st, s->d, cam, ln.d_lights, n_lights, depth,
                                depth == 10 ? 1 : 0, seed, b);
             HIP_TRY(hipGetLastError());
         }
@@ -1095,31 +1159,27 @@ static int render_batch(pt_film* f, const CamParams& cam, uint32_t n_lights, con
             sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
             sa.dist = b.sh_dist; sa.vis = b.sh_vis;
             sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
-            rc = launch_trace<TRACE_SHADOW_ANY>(s, sa);
+            rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &ctx);
             if (rc) return rc;
             sa.d_count = b.cnt + CNT_DEFER + depth;
             sa.count_mul = 1;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
-            rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa);
+            rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
             if (rc) return rc;
-            ScopedTimer tm(s, PT_KERNEL_ACCUMULATE);
-            hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, s->stream, n_lights, depth, b);
+            ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
+            hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, st, n_lights, depth, b);
             HIP_TRY(hipGetLastError());
         }
     }
+    if (after) HIP_TRY(hipStreamWaitEvent(st, after, 0));
     {
-        ScopedTimer tm(s, PT_KERNEL_ACCUMULATE);
-        hipLaunchKernelGGL(k_film, dim3((total + 255) / 256), dim3(256), 0, s->stream, f->d_sub, (uint32_t)sub.size(), f->d_groups,
-                           f->d_groups + f->cap_sub, n_groups, total, f->width, f->d_film, b);
+        ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
+        hipLaunchKernelGGL(k_film, dim3((total + 255) / 256), dim3(256), 0, st, ln.d_sub, (uint32_t)sub.size(), ln.d_groups,
+                           ln.d_groups + ln.cap_sub, n_groups, total, f->width, f->d_film, b);
         HIP_TRY(hipGetLastError());
     }
-    if (counts) {
-        uint32_t h[CNT_WORDS];
-        HIP_TRY(hipMemcpyAsync(h, b.cnt, sizeof(h), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        counts[0] += h[CNT_QUEUE + 0];
-        for (int d = 0; d <= 10; d++) { counts[1] += h[CNT_QUEUE + d]; counts[2] += (uint64_t)h[CNT_QUEUE + d + 1] * n_lights; }
-    }
+    HIP_TRY(hipEventRecord(ln.film_done, st));
+    HIP_TRY(hipMemcpyAsync(ln.h_cnt, b.cnt, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     return PT_OK;
 }
 
@@ -1147,6 +1207,7 @@ void pt_film_destroy(pt_film* f) {
     if (!f) return;
     (void)hipSetDevice(f->scene->device);
     (void)hipStreamSynchronize(f->scene->stream);
+    if (f->scene->stream2) (void)hipStreamSynchronize(f->scene->stream2);
     film_free_scratch(f);
     if (f->owns && f->d_film) (void)hipFree(f->d_film);
     delete f;
@@ -1305,47 +1366,10 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     }
     CamParams cp;
     fill_cam(cp, cam, f->width, f->height);
-    /* Paths per batch: as many as allowed (a trace launch pays a fixed ramp-up and tail, so
-     * longer queues run closer to the kernels' asymptotic rate: 32 -> 128 spp of 1080p per batch
-     * is +13 %), but the batch's scratch (96 bytes per path + 45 per shadow ray) stays within
-     * half of the GPU's memory and its shadow rays within what one trace launch accepts. */
-    size_t limit = batch_paths_limit();
-    {
-        const size_t L = (size_t)std::max(n_lights, 1);
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        limit = std::min(limit, (total_b / 2) / (96 + 45 * L));
-        limit = std::min(limit, (size_t)(PT_MAX_RAYS_PER_CALL / L));
-        limit = std::max<size_t>(limit, 4096);
-    }
-    /* PassDescriptor::clamp_bounds (reference integrator.cpp:164-183), then split into batches */
-    std::vector<SubPass> batch;
-    size_t batch_paths = 0;
-    uint64_t counts[3] = {0, 0, 0};
-    DLight hl[PT_MAX_LIGHTS];
-    for (int l = 0; l < n_lights; l++) {
-        hl[l].pos = v3(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
-        hl[l].color = v3(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
-    }
-    bool lights_uploaded = false;
-    auto flush = [&]() -> int {
-        if (batch.empty()) return PT_OK;
-        /* Large batches matter: a trace launch pays a fixed ramp-up and tail of a few hundred
-         * microseconds (the latency of its longest rays), so queues of tens of millions of rays
-         * are needed to run the kernels near their asymptotic rate. */
-        size_t cap = ((batch_paths + ((size_t)1 << 20) - 1) >> 20) << 20;
-        int r2 = film_ensure_scratch(f, cap, (uint32_t)n_lights, batch.size());
-        if (r2) return r2;
-        if (!lights_uploaded && n_lights > 0) {
-            HIP_TRY(hipMemcpyAsync(f->d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, s->stream));
-            lights_uploaded = true;
-        }
-        r2 = render_batch(f, cp, (uint32_t)n_lights, batch, (uint32_t)batch_paths, seed, stats ? counts : nullptr);
-        /* the host vectors of this batch must outlive the async copies */
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        batch.clear(); batch_paths = 0;
-        return r2;
-    };
+    /* PassDescriptor::clamp_bounds (reference integrator.cpp:164-183) */
+    struct Clamped { pt_tile_pass p; uint32_t bx; size_t padded; };
+    std::vector<Clamped> work;
+    size_t total_paths = 0, max_padded = 0;
     for (int i = 0; i < n_passes; i++) {
         pt_tile_pass p = passes[i];
         if (p.x < 0) p.x = 0;
@@ -1359,10 +1383,98 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         if (p.w <= 0 || p.h <= 0 || p.n_samples == 0) continue;
         uint32_t bx = (uint32_t)(p.w + 7) / 8, by = (uint32_t)(p.h + 7) / 8;
         size_t padded = (size_t)bx * by * 64;
-        if (padded > limit) return fail(PT_ERR_LIMIT, "one pass of this rectangle exceeds PT_BATCH_PATHS");
+        work.push_back({p, bx, padded});
+        total_paths += padded * p.n_samples;
+        max_padded = std::max(max_padded, padded);
+    }
+    /* Paths in flight: as many as allowed (a trace launch pays a fixed ramp-up and tail, the
+     * latency of its longest rays, so longer queues run closer to the kernels' asymptotic rate:
+     * 32 -> 128 spp of 1080p per call is +13 %), but the scratch (96 bytes per path + 45 per
+     * shadow ray) stays within half of the GPU's memory and a batch's shadow rays within what one
+     * trace launch accepts. */
+    size_t limit = batch_paths_limit();
+    {
+        const size_t L = (size_t)std::max(n_lights, 1);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        limit = std::min(limit, (total_b / 2) / (96 + 45 * L));
+        limit = std::max<size_t>(limit, 4096);
+    }
+    /* With two lanes the call's paths go out as (at least) two batches that run on two streams
+     * at once, so that one batch's kernels fill the compute units that the other's leave idle
+     * (the tail of every trace launch, the memory-bound shade and accumulate kernels).  Each
+     * lane gets half of the allowance.  The film kernels still run in batch order. */
+    int n_lanes = render_lanes();
+    size_t per_batch = limit;
+    if (n_lanes == 2) {
+        const size_t floor_paths = (size_t)1 << 22; /* below this a second batch costs more in launches than it hides */
+        per_batch = std::min(limit / 2, std::max((total_paths + 1) / 2, floor_paths) + max_padded - 1);
+        if (max_padded > per_batch || total_paths <= floor_paths) { n_lanes = 1; per_batch = limit; }
+    }
+    per_batch = std::min(per_batch, (size_t)(PT_MAX_RAYS_PER_CALL / (size_t)std::max(n_lights, 1)));
+    if (max_padded > per_batch) return fail(PT_ERR_LIMIT, "one pass of this rectangle exceeds PT_BATCH_PATHS");
+    LaunchCtx ctx[RENDER_LANES] = {{s->stream, s->d_spill}, {nullptr, nullptr}};
+    if (n_lanes == 2) {
+        rc = ensure_second_lane(s);
+        if (rc) return rc;
+        ctx[1] = {s->stream2, s->d_spill2};
+        /* the second stream starts after whatever the scene's stream already holds */
+        HIP_TRY(hipEventRecord(s->ev_order, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_order, 0));
+    }
+    uint64_t counts[3] = {0, 0, 0};
+    DLight hl[PT_MAX_LIGHTS];
+    for (int l = 0; l < n_lights; l++) {
+        hl[l].pos = v3(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
+        hl[l].color = v3(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
+    }
+    /* waits for a lane's batch and takes its counters */
+    auto harvest = [&](int li) -> int {
+        RenderLane& ln = f->lane[li];
+        if (!ln.in_flight) return PT_OK;
+        ln.in_flight = false;
+        HIP_TRY(hipStreamSynchronize(ctx[li].stream));
+        const uint32_t* h = ln.h_cnt;
+        counts[0] += h[CNT_QUEUE + 0];
+        for (int d = 0; d <= 10; d++) { counts[1] += h[CNT_QUEUE + d]; counts[2] += (uint64_t)h[CNT_QUEUE + d + 1] * ln.flight_lights; }
+        return PT_OK;
+    };
+    /* whatever happens, nothing of this call is in flight when it returns: the lanes' copies
+     * read `hl` and write the pinned counters */
+    struct Drain {
+        pt_film* f; LaunchCtx* ctx;
+        ~Drain() { for (int li = 0; li < RENDER_LANES; li++) if (f->lane[li].in_flight) { (void)hipStreamSynchronize(ctx[li].stream); f->lane[li].in_flight = false; } }
+    } drain{f, ctx};
+    std::vector<SubPass> batch;
+    size_t batch_paths = 0;
+    int next_lane = 0;
+    hipEvent_t last_film = nullptr;
+    auto flush = [&]() -> int {
+        if (batch.empty()) return PT_OK;
+        const int li = next_lane;
+        RenderLane& ln = f->lane[li];
+        int r2 = harvest(li);
+        if (r2) return r2;
+        size_t cap = ((batch_paths + ((size_t)1 << 20) - 1) >> 20) << 20;
+        r2 = lane_ensure_scratch(&ln, cap, (uint32_t)n_lights, batch.size());
+        if (r2) return r2;
+        if (n_lights > 0) HIP_TRY(hipMemcpyAsync(ln.d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, ctx[li].stream));
+        ln.h_sub.swap(batch);
+        ln.in_flight = true;
+        ln.flight_lights = (uint32_t)n_lights;
+        r2 = render_batch(f, ln, ctx[li], cp, (uint32_t)n_lights, (uint32_t)batch_paths, seed, last_film);
+        if (r2) return r2;
+        last_film = ln.film_done;
+        next_lane = (next_lane + 1) % n_lanes;
+        batch.clear(); batch_paths = 0;
+        return PT_OK;
+    };
+    for (const Clamped& c : work) {
+        const pt_tile_pass& p = c.p;
+        const size_t padded = c.padded;
         uint32_t done = 0;
         while (done < p.n_samples) {
-            size_t room = (limit - batch_paths) / padded;
+            size_t room = (per_batch - batch_paths) / padded;
             /* a different rectangle overlapping one already in the batch would race in the film kernel */
             bool overlap = false;
             for (const SubPass& e : batch)
@@ -1373,7 +1485,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
             SubPass sp{};
             sp.x = p.x; sp.y = p.y; sp.w = p.w; sp.h = p.h;
             sp.first_sample = p.first_sample + done; sp.n_samples = take;
-            sp.blocks_x = bx; sp.padded = (uint32_t)padded; sp.path0 = (uint32_t)batch_paths;
+            sp.blocks_x = c.bx; sp.padded = (uint32_t)padded; sp.path0 = (uint32_t)batch_paths;
             sp.group_first = (uint32_t)batch.size();
             for (uint32_t e = 0; e < batch.size(); e++)
                 if (batch[e].x == p.x && batch[e].y == p.y && batch[e].w == p.w && batch[e].h == p.h) { sp.group_first = batch[e].group_first; break; }
@@ -1384,6 +1496,8 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     }
     rc = flush();
     if (rc) return rc;
+    for (int li = 0; li < RENDER_LANES; li++) { rc = harvest(li); if (rc) return rc; }
+    if (s->pending.size() > 8192) { rc = resolve_timing(s); if (rc) return rc; }
     if (stats) {
         HIP_TRY(hipEventRecord(ev1, s->stream));
         HIP_TRY(hipEventSynchronize(ev1));

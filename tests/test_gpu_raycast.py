@@ -146,3 +146,30 @@ def test_lambertian_render_matches_oracle(scene_small):
     assert not np.array_equal(mirror, rgb)
     with pytest.raises(RuntimeError):
         film.render(pta.cli_camera(bounce_mode=7), pta.cli_lights(), [(0, 0, -1, -1, 0, 1)], seed=6)
+
+
+def test_two_render_lanes_match_one(scene_small, monkeypatch):
+    """PT_RENDER_LANES=2 keeps two batches in flight on two streams.  Cut into the same four
+    batches, the two-lane render must leave the very same film and ray counts as the one-lane
+    render: batches reach the film in order whichever stream they ran on."""
+    sc = scene_small
+    W, H, S = 1024, 512, 32  # 2^19 paths per sample, 2^24 in all
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    film = pta.Film(sc.gpu, W, H)
+    monkeypatch.setenv("PT_RENDER_LANES", "1")
+    monkeypatch.setenv("PT_BATCH_PATHS", str(1 << 22))
+    st1 = film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=11)
+    one, p1 = film.read()
+    film.zero()
+    monkeypatch.setenv("PT_RENDER_LANES", "2")
+    monkeypatch.setenv("PT_BATCH_PATHS", str(1 << 23))
+    st2 = film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=11)
+    two, p2 = film.read()
+    assert (p1 == S).all() and np.array_equal(p1, p2)
+    assert (st1.camera_samples, st1.closest_rays, st1.shadow_rays) == (st2.camera_samples, st2.closest_rays, st2.shadow_rays)
+    assert st1.camera_samples == W * H * S
+    assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
+    # and a second two-lane call on the same film reuses both lanes' scratch
+    film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, S, S)], seed=11)
+    _, p3 = film.read()
+    assert (p3 == 2 * S).all()
