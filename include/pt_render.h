@@ -134,6 +134,7 @@ struct Scene { /* integrator.h:20-33 */
     Real dof_dispersion;
     Color sky_color;
     bool lambertian_bounces; /* extension, default false: bounce by integrator.cpp:79-84 instead of the mirror direction of :104 */
+    bool bounded_shadow_rays; /* extension, default false: a light is hidden only by geometry nearer than it (kdtree.cpp:356-357) */
     Scene(std::string path);
     ~Scene();
 };

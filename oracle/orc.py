@@ -18,7 +18,8 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 class Camera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3),
                 ("image_plane_width", C.c_float), ("plane_of_focus_distance", C.c_float),
-                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3), ("bounce_mode", C.c_uint32)]
+                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3), ("bounce_mode", C.c_uint32),
+                ("shadow_mode", C.c_uint32)]
 
 
 class Light(C.Structure):
@@ -59,6 +60,7 @@ def lib():
         L.orc_raycast_counts.argtypes = [vp, i64, vp, vp, i32, vp, vp]
         L.orc_raycast_brute.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp, vp, i32]
         L.orc_shadow_visible.argtypes = [vp, i64, vp, vp, vp, vp, i32]
+        L.orc_occlusion_visible.argtypes = [vp, i64, vp, vp, vp, vp, i32]
         L.orc_camera_rays.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, u32, u64, vp, vp]
         L.orc_render.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, u32, u32, u64, vp, vp, vp, i32]
         L.orc_render_counting.argtypes = L.orc_render.argtypes
@@ -81,7 +83,7 @@ def _f32(a):
 
 
 def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of_focus_distance=1.0,
-                dof_dispersion=0.0, sky_color=(0, 0, 0), bounce_mode=0) -> Camera:
+                dof_dispersion=0.0, sky_color=(0, 0, 0), bounce_mode=0, shadow_mode=0) -> Camera:
     c = Camera()
     c.origin[:] = [float(np.float32(x)) for x in origin]
     c.direction[:] = [float(np.float32(x)) for x in direction]
@@ -91,6 +93,7 @@ def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of
     c.dof_dispersion = dof_dispersion
     c.sky_color[:] = list(sky_color)
     c.bounce_mode = bounce_mode   # 0: mirror (the reference as it stands), 1: Lambertian scatter
+    c.shadow_mode = shadow_mode   # 0: the reference's visibility test, 1: occlusion bounded at the light
     return c
 
 
@@ -173,12 +176,14 @@ class Scene:
         lib().orc_raycast_counts(self.h, o.shape[0], _p(o), _p(d), int(normalize), C.byref(nb), C.byref(nt))
         return nb.value, nt.value
 
-    def shadow_visible(self, o, d, dist, threads=8):
+    def shadow_visible(self, o, d, dist, threads=8, bounded=False):
+        """The reference's light-visibility test, or (bounded, an extension) no hit at t < dist."""
         o = _f32(o).reshape(-1, 3)
         d = _f32(d).reshape(-1, 3)
         dist = _f32(dist)
         vis = np.empty(o.shape[0], dtype=np.uint8)
-        lib().orc_shadow_visible(self.h, o.shape[0], _p(o), _p(d), _p(dist), _p(vis), threads)
+        fn = lib().orc_occlusion_visible if bounded else lib().orc_shadow_visible
+        fn(self.h, o.shape[0], _p(o), _p(d), _p(dist), _p(vis), threads)
         return vis
 
     def render(self, cam, lights, width, height, rect=None, first_sample=0, n_samples=1, seed=1, threads=8,
@@ -223,7 +228,8 @@ def philox(ctr, key):
     return out
 
 
-def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0, bounce_mode=0):
+def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0, bounce_mode=0,
+               shadow_mode=0):
     """Camera exactly as the reference's cli_render sets it up (cli_render.cpp:92-100)."""
     f32 = np.float32
     a = f32(angle)
@@ -236,7 +242,7 @@ def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture
     direction = direction / np.sqrt(f32(z), dtype=np.float32)
     origin = origin + np.array([0.0, 0.0, altitude], dtype=np.float32)
     return make_camera(origin, direction, (0, 0, 1), image_plane_width=0.75, plane_of_focus_distance=dof_distance,
-                       dof_dispersion=dof_aperture, bounce_mode=bounce_mode)
+                       dof_dispersion=dof_aperture, bounce_mode=bounce_mode, shadow_mode=shadow_mode)
 
 
 def cli_lights():

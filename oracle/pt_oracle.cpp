@@ -379,6 +379,22 @@ bool node_ray_test(const Node* n, const std::vector<Tri>& mesh, const CastingRay
     return false;
 }
 
+/* Extension with no counterpart in the reference (the bound its note at kdtree.cpp:356-357
+ * asks for): is any triangle hit at a ray parameter t < bound?  Every node whose box the ray
+ * hits (AABB::does_ray_intersect, as in ray_test's first statement) is searched, so the answer
+ * does not depend on a visit order. */
+bool node_any_within(const Node* n, const std::vector<Tri>& mesh, const CastingRay& c, float bound) {
+    if (n == nullptr || !box_hit(n->box, c)) return false;
+    if (n->leaf) {
+        for (size_t i = 0; i < n->tris.size(); i++) {
+            float t, u, v;
+            if (tri_hit(mesh[n->tris[i]], c.ray, t, u, v) && t < bound) return true;
+        }
+        return false;
+    }
+    return node_any_within(n->lo, mesh, c, bound) || node_any_within(n->hi, mesh, c, bound);
+}
+
 /* ------------------------------------------------------------ random stream */
 
 /* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11). */
@@ -535,7 +551,7 @@ struct PathCtx {
     V3 sky;
     uint64_t seed;
     uint32_t pixel, sample;
-    uint32_t bounce_mode;
+    uint32_t bounce_mode, shadow_mode;
     uint64_t closest_casts, shadow_casts;
     Counters* work_closest; /* optional: box/triangle tests spent on closest-hit casts */
     Counters* work_shadow;  /* ... and on shadow casts */
@@ -590,11 +606,18 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
         Ray shadow = make_ray(hit, to_light);
         Hit sh;
         ctx.shadow_casts++;
-        bool shadow_result = scene_ray_test(ctx.scene, shadow, sh, ctx.work_shadow);
         float dist = norm(to_light);
+        bool visible;
+        if (ctx.shadow_mode == 1) {
+            /* flagged extension: a light is hidden only by a triangle nearer than the light */
+            visible = !node_any_within(ctx.scene->root, ctx.scene->mesh, make_casting(shadow), dist);
+        } else {
+        bool shadow_result = scene_ray_test(ctx.scene, shadow, sh, ctx.work_shadow);
         /* :127 passes (ignore_u, ignore_v, shadow_param) where (t, u, v) are expected, so the
          * value compared with the light distance is the barycentric v of the closest hit. */
-        if (!shadow_result || sh.v > dist) {
+        visible = !shadow_result || sh.v > dist;
+        }
+        if (visible) {
             V3 contribution = lc / (dist * dist);
             float lambert = dot(n, to_light) / dist;
             lambert = real_max(0.0f, lambert);
@@ -767,6 +790,16 @@ void orc_shadow_visible(const orc_scene* s, int64_t n, const float* origins, con
     });
 }
 
+void orc_occlusion_visible(const orc_scene* s, int64_t n, const float* origins, const float* dirs, const float* max_t,
+                           uint8_t* visible, int threads) {
+    parallel_for(n, threads, [=](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; i++) {
+            Ray r = input_ray(origins, dirs, i, 0);
+            visible[i] = node_any_within(s->s.root, s->s.mesh, make_casting(r), max_t[i]) ? 0 : 1;
+        }
+    });
+}
+
 void orc_camera_rays(const orc_camera* cam, int width, int height, int x0, int y0, int w, int h, int jittered,
                      uint32_t sample, uint64_t seed, float* origins, float* dirs) {
     CameraBasis b = camera_basis(*cam, width, height);
@@ -803,6 +836,7 @@ static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_lig
         ctx.scene = &s->s; ctx.lights = lights; ctx.n_lights = n_lights;
         ctx.sky = mk(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
         ctx.bounce_mode = cam->bounce_mode;
+        ctx.shadow_mode = cam->shadow_mode;
         ctx.seed = seed; ctx.closest_casts = 0; ctx.shadow_casts = 0;
         Counters wc, ws;
         ctx.work_closest = count_work ? &wc : nullptr;

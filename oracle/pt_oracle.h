@@ -36,6 +36,8 @@ typedef struct orc_camera {
     float sky_color[3];
     uint32_t bounce_mode; /* 0: mirror bounce (the reference as it stands, integrator.cpp:104);
                              1: the Lambertian scatter of :79-84 without :104 (flagged extension) */
+    uint32_t shadow_mode; /* 0: the reference's visibility test (integrator.cpp:127-129);
+                             1: a light is hidden only by a hit nearer than it (flagged extension) */
 } orc_camera;
 
 typedef struct orc_light {
@@ -82,6 +84,11 @@ void orc_raycast_brute(const orc_scene* s, int64_t n, const float* origins, cons
  * nothing, or the barycentric v of its closest hit exceeds dist[i]. */
 void orc_shadow_visible(const orc_scene* s, int64_t n, const float* origins, const float* dirs,
                         const float* dist, uint8_t* visible, int threads);
+
+/* Extension, no counterpart in the reference: visible[i] = 1 iff no triangle, in any node whose
+ * box the ray hits, is hit at t < max_t[i].  What camera.shadow_mode = 1 uses for its lights. */
+void orc_occlusion_visible(const orc_scene* s, int64_t n, const float* origins, const float* dirs,
+                           const float* max_t, uint8_t* visible, int threads);
 
 /* Camera rays.  jittered=0: Integrator::get_ray_for_pixel (integrator.cpp:197-209).
  * jittered=1: the per-pixel ray of Integrator::perform_pass (integrator.cpp:248-259) with

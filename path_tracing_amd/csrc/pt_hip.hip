@@ -157,7 +157,8 @@ enum TraceMode {
     TRACE_CLOSEST_MESH = 0, /* outputs mesh index, t, u, v              (pt_raycast_closest) */
     TRACE_CLOSEST_FLAT = 1, /* outputs leaf-order position, t, u, v     (renderer)           */
     TRACE_SHADOW_ANY = 2,   /* visibility for dist >= 1; queues the others for the exact pass */
-    TRACE_SHADOW_EXACT = 3  /* visibility for the queued rays: closest hit, v > dist          */
+    TRACE_SHADOW_EXACT = 3, /* visibility for the queued rays: closest hit, v > dist          */
+    TRACE_SHADOW_BOUNDED = 4 /* visible iff no hit with t < dist; stops at the first such hit  */
 };
 
 struct TraceArgs {
@@ -191,13 +192,13 @@ struct TraceArgs {
  * Stack traffic is LDS only on the common path and needs no wait on global memory.
  *
  * Lanes whose ray is finished write their result and go idle; when enough lanes are idle the
- * wave hands them the next rays of its chunk (TRACE_CHUNK..16*TRACE_CHUNK consecutive rays,
+ * wave hands them the next rays of its chunk (TRACE_CHUNK..TRACE_MAX_CHUNK_MUL*TRACE_CHUNK consecutive rays,
  * one atomic on the queue head per chunk).  The loop ends when the queue is empty and every
  * lane is idle, so the grid always drains.
  */
 template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES_PER_EU))) void k_trace(DScene sc, TraceArgs a) {
-    constexpr bool ANY = (MODE == TRACE_SHADOW_ANY);
+    constexpr bool ANY = (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED);
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
     __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
     const uint32_t n = *a.d_count * a.count_mul;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     bool exhausted = false;               /* wave-uniform: the queue has no more chunks */
     /* The ray queue is handed out in chunks of consecutive rays: TRACE_CHUNK rays for short
      * queues (finer balance in the tail, and the rays in flight stay close together), growing
-     * to 16x that while every wave still gets TRACE_MIN_CHUNKS_PER_WAVE chunks on average, so
+     * to TRACE_MAX_CHUNK_MUL times that while every wave still gets TRACE_MIN_CHUNKS_PER_WAVE chunks on average, so
      * that a long queue does not saturate the atomic (one address sustains about 90 M/s).
      * A wave's first chunk is the one with its own number; later ones come from the shared
      * head, which therefore starts after the last wave's.  So a launch does not open with
@@ -260,6 +261,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             else {
                 ray_set_recip(L.r);
                 lane_start(L, sc.root_ref, sc.root, scene_tame);
+                /* a triangle counts only if it is strictly nearer than the best so far: starting
+                 * from the bound instead of infinity makes that "nearer than the light" */
+                if (MODE == TRACE_SHADOW_BOUNDED) L.best.t = dist;
                 ray = (int32_t)new_ray;
             }
         }
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
                     a.out_u[i] = L.found ? L.best.u : 0.0f;
                     a.out_v[i] = L.found ? L.best.v : 0.0f;
                 }
-            } else if (MODE == TRACE_SHADOW_ANY) {
+            } else if (ANY) {
                 a.vis[i] = L.found ? 0 : 1;
             } else {
                 a.vis[i] = (!L.found || L.best.v > dist) ? 1 : 0;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
          * into them. */
         if (starting) {
             if (MODE == TRACE_SHADOW_EXACT) new_ray = a.defer_list[new_ray];
-            if (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_EXACT) dist = a.dist[new_ray];
+            if (!CLOSEST_OUT) dist = a.dist[new_ray];
             L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
             L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
         }
@@ -842,7 +846,7 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     a.spill = here.spill;
     if (a.count_mul == 0) a.count_mul = 1;
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW, here.stream);
-    hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY)), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED)), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -930,6 +934,24 @@ int pt_raycast_shadow_dev(pt_scene* s, uint64_t n, const float* ox, const float*
     return launch_trace<TRACE_SHADOW_EXACT>(s, a);
 }
 
+int pt_raycast_occluded_dev(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                            const float* dy, const float* dz, const float* max_t, uint8_t* vis) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !max_t || !vis) return fail(PT_ERR_INVALID, "null array");
+    if (n > PT_MAX_RAYS_PER_CALL) return fail(PT_ERR_LIMIT, "more than PT_MAX_RAYS_PER_CALL rays in one call");
+    int rc = set_device(s);
+    if (rc) return rc;
+    if (s->n_tris == 0) { HIP_TRY(hipMemsetAsync(vis, 1, n, s->stream)); return PT_OK; }
+    uint32_t init[32] = {(uint32_t)n};
+    HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    TraceArgs a{};
+    a.rays = {ox, oy, oz, dx, dy, dz};
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 8;
+    a.dist = max_t; a.vis = vis;
+    return launch_trace<TRACE_SHADOW_BOUNDED>(s, a);
+}
+
 } // extern "C"
 
 /* Host-pointer forms: stage through device buffers that live for the call. */
@@ -964,8 +986,11 @@ int pt_raycast_closest(pt_scene* s, uint64_t n, const float* ox, const float* oy
     return PT_OK;
 }
 
-int pt_raycast_shadow(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
-                      const float* dy, const float* dz, const float* dist, uint8_t* vis) {
+typedef int (*visibility_dev_fn)(pt_scene*, uint64_t, const float*, const float*, const float*, const float*, const float*,
+                                 const float*, const float*, uint8_t*);
+
+static int visibility_from_host(visibility_dev_fn fn, pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz,
+                                const float* dx, const float* dy, const float* dz, const float* dist, uint8_t* vis) {
     if (!s) return fail(PT_ERR_INVALID, "null scene");
     if (n == 0) return PT_OK;
     if (!ox || !oy || !oz || !dx || !dy || !dz || !dist || !vis) return fail(PT_ERR_INVALID, "null array");
@@ -978,12 +1003,22 @@ int pt_raycast_shadow(pt_scene* s, uint64_t n, const float* ox, const float* oy,
         HIP_TRY(hipMemcpyAsync(in[k].p, src[k], n * 4, hipMemcpyHostToDevice, s->stream));
     }
     rc = out.alloc(n); if (rc) return rc;
-    rc = pt_raycast_shadow_dev(s, n, (float*)in[0].p, (float*)in[1].p, (float*)in[2].p, (float*)in[3].p, (float*)in[4].p,
-                               (float*)in[5].p, (float*)in[6].p, (uint8_t*)out.p);
+    rc = fn(s, n, (float*)in[0].p, (float*)in[1].p, (float*)in[2].p, (float*)in[3].p, (float*)in[4].p, (float*)in[5].p,
+            (float*)in[6].p, (uint8_t*)out.p);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(vis, out.p, n, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PT_OK;
+}
+
+int pt_raycast_shadow(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                      const float* dy, const float* dz, const float* dist, uint8_t* vis) {
+    return visibility_from_host(pt_raycast_shadow_dev, s, n, ox, oy, oz, dx, dy, dz, dist, vis);
+}
+
+int pt_raycast_occluded(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                        const float* dy, const float* dz, const float* max_t, uint8_t* vis) {
+    return visibility_from_host(pt_raycast_occluded_dev, s, n, ox, oy, oz, dx, dy, dz, max_t, vis);
 }
 
 } // extern "C"
@@ -1104,6 +1139,7 @@ static void fill_cam(CamParams& c, const pt_camera* cam, int width, int height) 
     c.dof_dispersion = cam->dof_dispersion;
     c.sky = v3(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
     c.bounce_mode = cam->bounce_mode;
+    c.shadow_mode = cam->shadow_mode;
 }
 
 /* Queues one batch (already clamped, grouped and numbered, in ln.h_sub) on the lane's stream
@@ -1158,14 +1194,19 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
             sa.count_mul = n_lights;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
             sa.dist = b.sh_dist; sa.vis = b.sh_vis;
-            sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
-            rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &ctx);
-            if (rc) return rc;
-            sa.d_count = b.cnt + CNT_DEFER + depth;
-            sa.count_mul = 1;
-            sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
-            rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
-            if (rc) return rc;
+            if (cam.shadow_mode == PT_SHADOW_BOUNDED) {
+                rc = launch_trace<TRACE_SHADOW_BOUNDED>(s, sa, &ctx);
+                if (rc) return rc;
+            } else {
+                sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
+                rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &ctx);
+                if (rc) return rc;
+                sa.d_count = b.cnt + CNT_DEFER + depth;
+                sa.count_mul = 1;
+                sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
+                rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
+                if (rc) return rc;
+            }
             ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
             hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, st, n_lights, depth, b);
             HIP_TRY(hipGetLastError());
@@ -1355,6 +1396,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         return fail(PT_ERR_INVALID, "bad argument");
     if (n_lights > PT_MAX_LIGHTS) return fail(PT_ERR_LIMIT, "more than PT_MAX_LIGHTS lights");
     if (cam->bounce_mode > PT_BOUNCE_LAMBERT) return fail(PT_ERR_INVALID, "unknown bounce_mode");
+    if (cam->shadow_mode > PT_SHADOW_BOUNDED) return fail(PT_ERR_INVALID, "unknown shadow_mode");
     pt_scene* s = f->scene;
     int rc = set_device(s);
     if (rc) return rc;

@@ -41,6 +41,7 @@ struct CamParams {
     V3f sky;
     int width, height;
     uint32_t bounce_mode;
+    uint32_t shadow_mode;
 };
 
 PT_HD void cam_basis(CamParams& c, V3f scene_up) {

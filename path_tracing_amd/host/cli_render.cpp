@@ -35,6 +35,7 @@ static const Option OPTIONS[] = {
     {"gpus", nullptr, "Same as --threads.", false},
     {"seed", "1", "Seed of the random stream.", false},
     {"lambertian", nullptr, "Bounce diffusely (reference integrator.cpp:79-84) instead of mirror-like.", true},
+    {"bounded-shadows", nullptr, "Let only geometry nearer than a light hide it (the reference does not bound shadow rays).", true},
     {"checkpoint", nullptr, "Also write the accumulators (energy sums, pass counts) to this file.", false},
     {"resume", nullptr, "Continue from accumulators written by --checkpoint (same size, same seed).", false},
     {"angle", "1", "Camera angle.", false},
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
     scene->plane_of_focus_distance = atof(vm["dof-distance"].c_str());
     scene->dof_dispersion = atof(vm["dof-aperture"].c_str());
     scene->lambertian_bounces = vm.count("lambertian") != 0;
+    scene->bounded_shadow_rays = vm.count("bounded-shadows") != 0;
 
     auto engine = new RenderEngine(atoi(vm["width"].c_str()), atoi(vm["height"].c_str()), scene);
     if (engine->workers.empty()) { cout << "No GPU available." << endl; return 1; }

@@ -161,6 +161,7 @@ Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integr
     dof_dispersion = 0.0;
     sky_color = Vec(0, 0, 0);
     lambertian_bounces = false;
+    bounded_shadow_rays = false;
     mesh = nullptr; lights = nullptr; tree = nullptr;
     pth_scene* built = pth_scene_from_stl(path.c_str(), 0);
     if (built == nullptr) {
@@ -300,6 +301,7 @@ static void fill_camera(pt_camera& c, const Scene* s) {
     c.plane_of_focus_distance = s->plane_of_focus_distance;
     c.dof_dispersion = s->dof_dispersion;
     c.bounce_mode = s->lambertian_bounces ? PT_BOUNCE_LAMBERT : PT_BOUNCE_MIRROR;
+    c.shadow_mode = s->bounded_shadow_rays ? PT_SHADOW_BOUNDED : PT_SHADOW_REFERENCE;
 }
 
 static void fill_lights(vector<pt_light>& out, const Scene* s) {

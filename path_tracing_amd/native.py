@@ -47,7 +47,8 @@ class FlatScene(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3),
                 ("image_plane_width", C.c_float), ("plane_of_focus_distance", C.c_float),
-                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3), ("bounce_mode", C.c_uint32)]
+                ("dof_dispersion", C.c_float), ("sky_color", C.c_float * 3), ("bounce_mode", C.c_uint32),
+                ("shadow_mode", C.c_uint32)]
 
 
 class Light(C.Structure):
@@ -94,7 +95,7 @@ def host_lib():
 
 HIP_SYMBOLS = [
     "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_raycast_closest", "pt_raycast_closest_dev",
-    "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_film_create",
+    "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_raycast_occluded", "pt_raycast_occluded_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_film_create",
     "pt_film_destroy", "pt_film_zero", "pt_film_device_ptr", "pt_film_read", "pt_film_add", "pt_films_reduce", "pt_render_passes",
     "pt_camera_rays_dev", "pt_last_error", "pt_build_info",
 ]
@@ -125,6 +126,8 @@ def hip_lib():
         L.pt_raycast_closest_dev.argtypes = [vp, u64] + [vp] * 10
         L.pt_raycast_shadow.argtypes = [vp, u64] + [vp] * 8
         L.pt_raycast_shadow_dev.argtypes = [vp, u64] + [vp] * 8
+        L.pt_raycast_occluded.argtypes = [vp, u64] + [vp] * 8
+        L.pt_raycast_occluded_dev.argtypes = [vp, u64] + [vp] * 8
         L.pt_scene_sync.argtypes = [vp]
         L.pt_scene_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(u64)]
         L.pt_film_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]

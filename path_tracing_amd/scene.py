@@ -23,7 +23,7 @@ def _f32(a):
 
 
 def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of_focus_distance=1.0,
-                dof_dispersion=0.0, sky_color=(0, 0, 0), bounce_mode=0) -> Camera:
+                dof_dispersion=0.0, sky_color=(0, 0, 0), bounce_mode=0, shadow_mode=0) -> Camera:
     c = Camera()
     c.origin[:] = [float(np.float32(x)) for x in origin]
     c.direction[:] = [float(np.float32(x)) for x in direction]
@@ -33,6 +33,7 @@ def make_camera(origin, direction, up=(0, 0, 1), image_plane_width=1.0, plane_of
     c.dof_dispersion = dof_dispersion
     c.sky_color[:] = list(sky_color)
     c.bounce_mode = bounce_mode   # 0: mirror (the reference as it stands), 1: Lambertian scatter
+    c.shadow_mode = shadow_mode   # 0: the reference's visibility test, 1: occlusion bounded at the light
     return c
 
 
@@ -45,7 +46,7 @@ def make_lights(lights):
 
 
 def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture=0.0, dof_distance=1.0,
-               bounce_mode=0) -> Camera:
+               bounce_mode=0, shadow_mode=0) -> Camera:
     """Camera as the reference's cli_render derives it from its flags (cli_render.cpp:92-100)."""
     f32 = np.float32
     a = f32(angle)
@@ -57,7 +58,8 @@ def cli_camera(angle=1.0, altitude=0.2, distance=5.0, z_offset=0.0, dof_aperture
     direction = direction / np.sqrt(f32(z), dtype=np.float32)
     origin = origin + np.array([0.0, 0.0, altitude], dtype=np.float32)
     return make_camera(origin, direction, (0, 0, 1), image_plane_width=0.75,
-                       plane_of_focus_distance=dof_distance, dof_dispersion=dof_aperture, bounce_mode=bounce_mode)
+                       plane_of_focus_distance=dof_distance, dof_dispersion=dof_aperture, bounce_mode=bounce_mode,
+                       shadow_mode=shadow_mode)
 
 
 def cli_lights():
@@ -184,15 +186,17 @@ class GpuScene:
               "pt_raycast_closest")
         return idx, t, u, v
 
-    def raycast_shadow(self, origins, dirs, dist):
+    def raycast_shadow(self, origins, dirs, dist, bounded=False):
+        """Visibility per ray: the reference's test, or (bounded) no hit nearer than dist."""
         o = _f32(origins).reshape(-1, 3)
         d = _f32(dirs).reshape(-1, 3)
         dist = _f32(dist).reshape(-1)
         n = o.shape[0]
         cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
         vis = np.empty(n, dtype=np.uint8)
-        check(native.hip_lib().pt_raycast_shadow(self.h, n, *[_p(c) for c in cols], _p(dist), _p(vis)),
-              "pt_raycast_shadow")
+        L = native.hip_lib()
+        name = "pt_raycast_occluded" if bounded else "pt_raycast_shadow"
+        check(getattr(L, name)(self.h, n, *[_p(c) for c in cols], _p(dist), _p(vis)), name)
         return vis
 
     # -- device-pointer entry points (torch tensors on this device) ----------------------
@@ -204,12 +208,12 @@ class GpuScene:
             self.h, n, *ptrs, C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_t.data_ptr()),
             C.c_void_p(out_u.data_ptr()), C.c_void_p(out_v.data_ptr())), "pt_raycast_closest_dev")
 
-    def raycast_shadow_dev(self, rays, dist, out_vis):
+    def raycast_shadow_dev(self, rays, dist, out_vis, bounded=False):
         n = rays[0].numel()
         ptrs = [C.c_void_p(r.data_ptr()) for r in rays]
-        check(native.hip_lib().pt_raycast_shadow_dev(
-            self.h, n, *ptrs, C.c_void_p(dist.data_ptr()), C.c_void_p(out_vis.data_ptr())),
-            "pt_raycast_shadow_dev")
+        name = "pt_raycast_occluded_dev" if bounded else "pt_raycast_shadow_dev"
+        check(getattr(native.hip_lib(), name)(
+            self.h, n, *ptrs, C.c_void_p(dist.data_ptr()), C.c_void_p(out_vis.data_ptr())), name)
 
     def camera_rays_dev(self, cam: Camera, width, height, rect, jittered, sample, seed, out6):
         x, y, w, h = rect

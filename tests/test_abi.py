@@ -32,4 +32,4 @@ def test_host_library_exports_header():
 def test_record_sizes_match_header():
     assert C.sizeof(native.FlatNode) == 64
     assert native.NODE_DTYPE.itemsize == 64 and native.ISECT_DTYPE.itemsize == 48 and native.SHADE_DTYPE.itemsize == 64
-    assert C.sizeof(native.Camera) == 16 * 4 and C.sizeof(native.Light) == 24 and C.sizeof(native.TilePass) == 24
+    assert C.sizeof(native.Camera) == 17 * 4 and C.sizeof(native.Light) == 24 and C.sizeof(native.TilePass) == 24

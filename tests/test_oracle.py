@@ -165,3 +165,32 @@ def test_lambertian_mode_is_a_separate_stream(scene_small):
     # both modes cast at least the camera rays, at most 11 closest-hit rays per sample
     n = 64 * 48 * 2
     assert n <= cl[0] <= 11 * n and n <= cm[0] <= 11 * n
+
+
+def test_bounded_shadow_mode(scene_small):
+    """shadow_mode 1 (a light is hidden only by geometry nearer than it).  On the stand-in scene:
+    same rays cast, same result whatever the thread count.  In a room with a floor, a ceiling
+    and a light between them, every unbounded shadow ray goes on past the light into the other
+    slab, so the reference's test leaves the room (nearly) dark, and the bounded test lights it."""
+    sc = scene_small
+    lights = orc.cli_lights()
+    ref, pr, cr = sc.oracle.render(orc.cli_camera(), lights, 64, 48, None, 0, 2, seed=4)
+    bnd, pb, cb = sc.oracle.render(orc.cli_camera(shadow_mode=1), lights, 64, 48, None, 0, 2, seed=4)
+    bnd2, _, _ = sc.oracle.render(orc.cli_camera(shadow_mode=1), lights, 64, 48, None, 0, 2, seed=4, threads=3)
+    assert np.array_equal(pr, pb) and np.array_equal(cr, cb)
+    assert np.array_equal(bits(bnd), bits(bnd2))
+
+    def slab(z, flip):
+        q = np.array([[-10, -10, z], [10, -10, z], [10, 10, z], [-10, 10, z]], np.float32)
+        a, b = (q[[0, 1, 2]], q[[0, 2, 3]]) if not flip else (q[[0, 2, 1]], q[[0, 3, 2]])
+        return np.stack([a.reshape(9), b.reshape(9)])
+    room = orc.Scene(np.concatenate([slab(0.0, False), slab(3.0, True)]).astype(np.float32), threads=1)
+    light = [((0.0, 0.0, 1.5), (9.0, 9.0, 9.0))]
+    out = []
+    for mode in (0, 1):
+        cam = orc.make_camera((0.3, 0.2, 2.5), (0.0, 0.0, -1.0), up=(0, 1, 0), image_plane_width=0.75, shadow_mode=mode)
+        rgb, _, counts = room.render(cam, light, 32, 24, None, 0, 4, seed=2)
+        out.append((rgb, counts))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert out[1][0].min() > 1.0          # every pixel sees the lit floor
+    assert out[0][0].sum() < 0.05 * out[1][0].sum()
