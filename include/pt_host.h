@@ -28,7 +28,8 @@ void       pth_scene_destroy(pth_scene* s);
 
 int64_t              pth_num_triangles(const pth_scene* s);
 const pt_flat_scene* pth_flat_scene(const pth_scene* s);
-/* Seconds spent in the vertex-normal pass, the tree build and the flattening. */
+/* Seconds spent in the vertex-normal pass, the tree build and the flattening.  With more than
+ * one thread the first two run side by side, so their sum exceeds the wall time. */
 void pth_timings(const pth_scene* s, double out[3]);
 
 /* Per-triangle data in mesh order, 30 floats each: p0 p1 p2 edge01 edge02 normal base_normal

@@ -56,12 +56,28 @@ struct Mesh {
     std::vector<float> bmin[3], bmax[3];               /* triangle AABBs per axis */
 };
 
+/* Runs fn(first, last) over [0, n) cut into one contiguous range per thread. */
+template <class F>
+void parallel_ranges(int64_t n, int threads, F fn) {
+    int64_t t = std::max<int64_t>(1, std::min<int64_t>(threads, n / 16384));
+    if (t == 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    for (int64_t k = 0; k < t; k++) pool.emplace_back([=]() { fn(n * k / t, n * (k + 1) / t); });
+    for (auto& th : pool) th.join();
+}
+
+int default_threads() {
+    int t = (int)std::thread::hardware_concurrency();
+    return t > 0 ? t : 8;
+}
+
 /* Triangle::Triangle (reference utils.cpp:116-129). */
-void mesh_from_soup(Mesh& m, const float* v, int64_t n) {
+void mesh_from_soup(Mesh& m, const float* v, int64_t n, int threads) {
     m.n = n;
     m.p0.resize(n); m.p1.resize(n); m.p2.resize(n); m.normal.resize(n);
     for (int a = 0; a < 3; a++) { m.bmin[a].resize(n); m.bmax[a].resize(n); }
-    for (int64_t i = 0; i < n; i++) {
+    parallel_ranges(n, threads, [&m, v](int64_t first, int64_t last) {
+    for (int64_t i = first; i < last; i++) {
         const float* q = v + 9 * i;
         F3 a = f3(q[0], q[1], q[2]), b = f3(q[3], q[4], q[5]), c = f3(q[6], q[7], q[8]);
         m.p0[i] = a; m.p1[i] = b; m.p2[i] = c;
@@ -72,6 +88,7 @@ void mesh_from_soup(Mesh& m, const float* v, int64_t n) {
             m.bmax[k][i] = sel_max(sel_max(pa[k], pb[k]), pc[k]);
         }
     }
+    });
 }
 
 struct VKey {
@@ -93,29 +110,69 @@ inline VKey vkey(F3 p) { VKey k; k.a = fbits(p.x); k.b = fbits(p.y); k.c = fbits
 
 /* compute_barycentric_normals (reference stlreader.cpp:62-81): a corner's normal is the
  * normalised sum, taken in mesh order, of the face normals of all corners at the same
- * position.  A hash of vertex positions replaces the reference's ordered map; the running
- * sum visits contributions in the same order as the reference's per-vertex list. */
-void vertex_normals(Mesh& m) {
-    std::unordered_map<VKey, int32_t, VKeyHash> ids;
-    ids.reserve((size_t)m.n * 2);
-    std::vector<int32_t> corner((size_t)m.n * 3);
-    std::vector<F3> sum;
-    for (int64_t i = 0; i < m.n; i++) {
-        const F3 c[3] = {m.p0[i], m.p1[i], m.p2[i]};
-        for (int k = 0; k < 3; k++) {
-            auto it = ids.find(vkey(c[k]));
-            int32_t id;
-            if (it == ids.end()) { id = (int32_t)sum.size(); ids.emplace(vkey(c[k]), id); sum.push_back(f3(0, 0, 0)); }
-            else id = it->second;
-            corner[3 * i + k] = id;
-            sum[id] = add(sum[id], m.normal[i]);
+ * position.  Hash tables of vertex positions replace the reference's ordered map.  Each thread
+ * owns the positions whose hash falls in its share, scans all corners in mesh order and sums
+ * only its own, so every running sum visits its contributions in the same order as the
+ * reference's per-vertex list whatever the thread count. */
+void vertex_normals(Mesh& m, int threads) {
+    const int64_t n = m.n;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(threads, 64), n / 16384));
+    std::vector<int32_t> corner((size_t)n * 3); /* index into the owner's sums */
+    std::vector<uint8_t> owner((size_t)n * 3);
+    std::vector<std::vector<F3>> sums((size_t)T);
+    auto job = [&](int me) {
+        std::vector<F3>& sum = sums[(size_t)me];
+        std::vector<VKey> keys;
+        size_t cap = 1024; /* open addressing, linear probing, at most half full */
+        while (cap < (size_t)(n / T) * 2) cap <<= 1;
+        std::vector<int32_t> slot(cap, -1);
+        VKeyHash hasher;
+        for (int64_t i = 0; i < n; i++) {
+            const F3 c[3] = {m.p0[i], m.p1[i], m.p2[i]};
+            for (int k = 0; k < 3; k++) {
+                const VKey key = vkey(c[k]);
+                const uint64_t h = (uint64_t)hasher(key);
+                if ((int)(((h >> 32) * (uint64_t)T) >> 32) != me) continue;
+                size_t at = (size_t)h & (cap - 1);
+                int32_t id;
+                while ((id = slot[at]) >= 0 && !(keys[(size_t)id] == key)) at = (at + 1) & (cap - 1);
+                if (id < 0) {
+                    id = (int32_t)keys.size();
+                    keys.push_back(key);
+                    sum.push_back(f3(0, 0, 0));
+                    slot[at] = id;
+                    if (keys.size() * 2 > cap) { /* rebuild at twice the size */
+                        cap <<= 1;
+                        slot.assign(cap, -1);
+                        for (size_t q = 0; q < keys.size(); q++) {
+                            size_t z = (size_t)hasher(keys[q]) & (cap - 1);
+                            while (slot[z] >= 0) z = (z + 1) & (cap - 1);
+                            slot[z] = (int32_t)q;
+                        }
+                    }
+                }
+                corner[(size_t)(3 * i + k)] = id;
+                owner[(size_t)(3 * i + k)] = (uint8_t)me;
+                sum[(size_t)id] = add(sum[(size_t)id], m.normal[i]);
+            }
         }
+        for (auto& v : sum) v = unit(v);
+    };
+    if (T == 1) job(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++) pool.emplace_back(job, t);
+        for (auto& th : pool) th.join();
     }
-    for (auto& s : sum) s = unit(s);
-    m.vn0.resize(m.n); m.vn1.resize(m.n); m.vn2.resize(m.n);
-    for (int64_t i = 0; i < m.n; i++) {
-        m.vn0[i] = sum[corner[3 * i]]; m.vn1[i] = sum[corner[3 * i + 1]]; m.vn2[i] = sum[corner[3 * i + 2]];
-    }
+    m.vn0.resize(n); m.vn1.resize(n); m.vn2.resize(n);
+    parallel_ranges(n, threads, [&](int64_t first, int64_t last) {
+        for (int64_t i = first; i < last; i++) {
+            const size_t c = (size_t)(3 * i);
+            m.vn0[i] = sums[owner[c]][(size_t)corner[c]];
+            m.vn1[i] = sums[owner[c + 1]][(size_t)corner[c + 1]];
+            m.vn2[i] = sums[owner[c + 2]][(size_t)corner[c + 2]];
+        }
+    });
 }
 
 /* read_stl (reference stlreader.cpp:10-43): binary only, 80-byte header ignored, file
@@ -161,46 +218,65 @@ struct BNode {
 struct Builder {
     const Mesh* m;
     std::vector<int32_t> lists[2][3]; /* [0]=by minimum, [1]=by maximum; per axis */
+    std::vector<float> vals[2][3];    /* the coordinate each list is sorted by, in list order */
     std::vector<uint8_t> low_side;    /* per triangle, scratch of the node that owns it */
+    std::vector<int32_t> rank_x;      /* per triangle: its place in the owning node's by-min-x segment */
     int spawn_depth = 0;
     int wide_threads = 1;
 
     const float* coord(int mm, int axis) const { return mm == 0 ? m->bmin[axis].data() : m->bmax[axis].data(); }
 
-    /* Best split on one axis; candidates in ascending order, strict '<' keeps the first
-     * (reference kdtree.cpp:104-145). */
-    void best_on_axis(int axis, int64_t begin, int64_t count, int inc, float& score_io, float& split_io, int& axis_io) const {
-        const int32_t* ours = lists[0][0].data() + begin;
-        const float* mx = m->bmax[axis].data();
-        for (int64_t tt = 0; tt < count; tt += inc) {
-            float sample = mx[ours[tt]];
-            int side[2];
-            for (int mm = 0; mm < 2; mm++) {
-                const int32_t* l = lists[mm][axis].data() + begin;
-                const float* c = coord(mm, axis);
-                uint64_t low = 0, high = (uint64_t)count;
-                while (low + 1 < high) {
-                    uint64_t mid = (low + high) / 2;
-                    if (c[l[mid]] <= sample) low = mid; else high = mid;
-                }
-                side[mm] = mm == 0 ? (int)(low + 1) : (int)((uint64_t)count - high);
-            }
-            float score = sel_max((float)side[0], (float)side[1]);
-            if (score < score_io) { score_io = score; split_io = sample; axis_io = axis; }
+    /* Best split on one axis (reference kdtree.cpp:104-145).  The reference walks the candidates
+     * -- the maximum on this axis of every inc-th triangle of the by-min-x list -- in list order,
+     * finds count_low = #(min <= s) and count_high = #(max > s) with two binary searches each,
+     * and keeps the first candidate with the strictly smallest max(count_low, count_high).
+     * Here the candidates are met in ascending order of s instead, along the by-max list, so the
+     * two counts are running positions in the sorted value arrays (one pass over the node, no
+     * searches); "first in list order" becomes "smallest place in the by-min-x list among equal
+     * scores".  The binary searches never inspect element 0, which is harmless: s is the
+     * maximum of a triangle of the node, so the smallest minimum and the smallest maximum are
+     * both <= s. */
+    void best_on_axis(int axis, int64_t begin, int64_t count, int inc, float& score_out, float& split_out, int& axis_out) const {
+        const int32_t* imax = lists[1][axis].data() + begin;
+        const float* vmax = vals[1][axis].data() + begin;
+        const float* vmin = vals[0][axis].data() + begin;
+        const int32_t* rk = rank_x.data();
+        const int32_t mask = inc - 1; /* inc is a power of two */
+        int64_t n_min = 0, n_max = 0; /* #(min <= s), #(max <= s) */
+        float best = score_out, best_split = split_out;
+        int32_t best_place = INT32_MAX;
+        for (int64_t j = 0; j < count; j++) {
+            const int32_t place = rk[imax[j]];
+            if (place & mask) continue;
+            const float s = vmax[j];
+            while (n_min < count && vmin[n_min] <= s) n_min++;
+            if (n_max <= j) n_max = j + 1;
+            while (n_max < count && vmax[n_max] <= s) n_max++;
+            const float score = sel_max((float)(int)n_min, (float)(int)(count - n_max));
+            if (score < best || (score == best && place < best_place)) { best = score; best_split = s; best_place = place; }
         }
+        if (best_place != INT32_MAX) { score_out = best; split_out = best_split; axis_out = axis; }
     }
 
-    /* Stable partition of one list segment: low-side triangles first, order kept on both sides. */
+    /* Stable partition of one list segment (and of its value array): low-side triangles first,
+     * order kept on both sides. */
     int64_t partition(int mm, int axis, int64_t begin, int64_t count) {
         int32_t* a = lists[mm][axis].data() + begin;
+        float* v = vals[mm][axis].data() + begin;
         std::vector<int32_t> high;
+        std::vector<float> high_v;
         high.reserve((size_t)count / 2 + 8);
+        high_v.reserve((size_t)count / 2 + 8);
         int64_t nl = 0;
         for (int64_t i = 0; i < count; i++) {
             int32_t t = a[i];
-            if (low_side[t]) a[nl++] = t; else high.push_back(t);
+            float x = v[i];
+            if (low_side[t]) { a[nl] = t; v[nl] = x; nl++; } else { high.push_back(t); high_v.push_back(x); }
         }
-        if (!high.empty()) memcpy(a + nl, high.data(), high.size() * sizeof(int32_t));
+        if (!high.empty()) {
+            memcpy(a + nl, high.data(), high.size() * sizeof(int32_t));
+            memcpy(v + nl, high_v.data(), high_v.size() * sizeof(float));
+        }
         return nl;
     }
 
@@ -217,6 +293,7 @@ struct Builder {
             n->bmin[a] = lo; n->bmax[a] = hi;
         }
         if (count <= LEAF_THRESHOLD || depth >= MAXIMUM_DEPTH) { n->leaf = true; return n; }
+        for (int64_t i = 0; i < count; i++) rank_x[ours[i]] = (int32_t)i;
         int inc = 8;                 /* reference kdtree.cpp:92-98 */
         if (count < 10000) inc = 4;
         if (count < 1000) inc = 2;
@@ -232,7 +309,12 @@ struct Builder {
             for (int a = 0; a < 3; a++) th[a].join();
             for (int a = 0; a < 3; a++) if (sc[a] < best_score) { best_score = sc[a]; best_split = sp[a]; best_axis = ax[a]; }
         } else {
-            for (int a = 0; a < 3; a++) best_on_axis(a, begin, count, inc, best_score, best_split, best_axis);
+            for (int a = 0; a < 3; a++) {
+                float sc = inf, sp = 0.0f;
+                int ax = -1;
+                best_on_axis(a, begin, count, inc, sc, sp, ax);
+                if (sc < best_score) { best_score = sc; best_split = sp; best_axis = ax; }
+            }
         }
         n->axis = best_axis; n->split = best_split;
         /* low iff the triangle's minimum on the split axis is <= the split height; every other
@@ -277,11 +359,15 @@ struct Builder {
                 for (int64_t i = 0; i < n; i++) l[i] = (int32_t)i;
                 const float* c = coord(mm, axis);
                 std::sort(l.begin(), l.end(), [c](const int& a, const int& b) { return c[a] < c[b]; });
+                std::vector<float>& v = vals[mm][axis];
+                v.resize((size_t)n);
+                for (int64_t i = 0; i < n; i++) v[i] = c[l[i]];
             };
             if (threads > 1) pool.emplace_back(job); else job();
         }
         for (auto& t : pool) t.join();
         low_side.assign((size_t)n, 0);
+        rank_x.assign((size_t)n, 0);
         spawn_depth = 0;
         while ((1 << spawn_depth) < threads) spawn_depth++;
         wide_threads = threads;
@@ -334,13 +420,14 @@ inline float plane_of(F3 nrm, F3 a, F3 b, F3 c) {
     return (float)((double)s / 3.0);
 }
 
-void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm, Flat& f) {
+void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm, Flat& f, int threads) {
     uint32_t max_depth = 0;
     f.nodes.clear();
     uint32_t root_ref = flatten_rec(root, f, max_depth);
     f.tris.resize((size_t)m.n);
     f.shade.resize((size_t)m.n);
-    for (int64_t k = 0; k < m.n; k++) {
+    parallel_ranges(m.n, threads, [&m, &perm, &f](int64_t first, int64_t last) {
+    for (int64_t k = first; k < last; k++) {
         int32_t i = perm[(size_t)k];
         pt_tri_isect& ti = f.tris[(size_t)k];
         F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
@@ -359,6 +446,7 @@ void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm,
         F3 d1 = unit(e1); /* hit_triangle->edge01.normalized(), integrator.cpp:82 */
         ts.d1_x = d1.x; ts.d1_y = d1.y; ts.d1_z = d1.z;
     }
+    });
     mark_leaf_counts(root, f);
     memset(&f.desc, 0, sizeof(f.desc));
     f.desc.n_nodes = f.nodes.size();
@@ -401,19 +489,26 @@ struct pth_scene {
 };
 
 static pth_scene* finish(pth_scene* s, int threads) {
-    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 8; }
+    if (threads <= 0) threads = default_threads();
     if (s->mesh.n >= (int64_t)PT_MAX_TRIANGLES) { delete s; return nullptr; }
-    double t0 = now_s();
-    vertex_normals(s->mesh);
+    /* The tree needs only the triangles' boxes and the vertex normals only their positions, so
+     * with more than one thread the two run side by side (half of the threads each; the
+     * normals finish first and the build's own threads then have the machine). */
+    double t0 = now_s(), t_normals_end = t0;
+    std::thread normals;
+    if (threads > 1) normals = std::thread([s, threads, &t_normals_end]() { vertex_normals(s->mesh, std::max(1, threads / 2)); t_normals_end = now_s(); });
+    else { vertex_normals(s->mesh, 1); t_normals_end = now_s(); }
     double t1 = now_s();
     Builder b;
     b.m = &s->mesh;
     s->root = b.run(threads);
     s->perm.swap(b.lists[0][0]);
     double t2 = now_s();
-    flatten(s->mesh, s->root, s->perm, s->flat);
+    if (normals.joinable()) normals.join();
+    double t2b = now_s();
+    flatten(s->mesh, s->root, s->perm, s->flat, threads);
     double t3 = now_s();
-    s->t_normals = t1 - t0; s->t_build = t2 - t1; s->t_flatten = t3 - t2;
+    s->t_normals = t_normals_end - t0; s->t_build = t2 - t1; s->t_flatten = t3 - t2b;
     return s;
 }
 
@@ -423,14 +518,14 @@ pth_scene* pth_scene_from_stl(const char* path, int threads) {
     std::vector<float> soup;
     if (!path || !load_stl(path, soup)) return nullptr;
     pth_scene* s = new pth_scene();
-    mesh_from_soup(s->mesh, soup.data(), (int64_t)(soup.size() / 9));
+    mesh_from_soup(s->mesh, soup.data(), (int64_t)(soup.size() / 9), threads > 0 ? threads : default_threads());
     return finish(s, threads);
 }
 
 pth_scene* pth_scene_from_triangles(const float* verts, int64_t n, int threads) {
     if (n < 0 || (n > 0 && !verts)) return nullptr;
     pth_scene* s = new pth_scene();
-    mesh_from_soup(s->mesh, verts, n);
+    mesh_from_soup(s->mesh, verts, n, threads > 0 ? threads : default_threads());
     return finish(s, threads);
 }
 
