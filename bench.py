@@ -84,11 +84,19 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    def note(msg):
+        # progress on stderr: big scenes spend minutes before the first kernel
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
     W, H, spp = args.width, args.height, args.spp_per_step
     t0 = time.time()
     tris = pta.meshgen.standin_scene(args.level)
+    note("mesh of %d triangles generated in %.1f s" % (len(tris), time.time() - t0))
+    t0 = time.time()
     host = pta.HostScene(tris, threads=host_threads(world))
     t_prepare = time.time() - t0
+    note("normals, tree and flat arrays in %.1f s" % t_prepare)
     gpu = pta.GpuScene(host, local_rank)
     film_t = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
@@ -105,6 +113,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     gpu.sync()
+    note("warm-up done")
     reduce_film(film_t, dst=0)  # untimed: first use of the collective (communicator, kernels)
     torch.cuda.synchronize()
     film.zero()
