@@ -1401,10 +1401,13 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     int rc = set_device(s);
     if (rc) return rc;
     if (stats) memset(stats, 0, sizeof(*stats));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct CallEvents { /* destroyed on every way out */
+        hipEvent_t a = nullptr, b = nullptr;
+        ~CallEvents() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
     if (stats) {
-        HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
-        HIP_TRY(hipEventRecord(ev0, s->stream));
+        HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventRecord(ev.a, s->stream));
     }
     CamParams cp;
     fill_cam(cp, cam, f->width, f->height);
@@ -1541,11 +1544,10 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     for (int li = 0; li < RENDER_LANES; li++) { rc = harvest(li); if (rc) return rc; }
     if (s->pending.size() > 8192) { rc = resolve_timing(s); if (rc) return rc; }
     if (stats) {
-        HIP_TRY(hipEventRecord(ev1, s->stream));
-        HIP_TRY(hipEventSynchronize(ev1));
+        HIP_TRY(hipEventRecord(ev.b, s->stream));
+        HIP_TRY(hipEventSynchronize(ev.b));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
         stats->camera_samples = counts[0]; stats->closest_rays = counts[1]; stats->shadow_rays = counts[2];
         stats->gpu_ms = ms;
     }
