@@ -237,7 +237,7 @@ def main():
                         "kernel": "k_trace<closest>",
                         "note": "achieved prices every box/triangle test of the reference's visit order at HBM cost; the scene "
                                 "(166 MB) sits in L2 + Infinity Cache, so `traffic` (measured HBM-side bytes per launch) is "
-                                "far lower and frac can exceed 1 -- the kernel is bound by vector-instruction issue and latency",
+                                "far lower and frac can exceed 1 -- the kernel is bound by the compute units' own vector-memory path (address unit and L1 about 90-98 % busy fetching one 64-byte record per lane and round) together with vector-instruction issue (about 80 %)",
                         "algorithmic_bytes_per_ray": round(float(b_closest), 1),
                         "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
                         "rays_per_launch": round(closest / launches_c, 1),
