@@ -82,6 +82,9 @@ struct RaySoAW {
 #ifndef TRACE_MAX_CHUNK_MUL
 #define TRACE_MAX_CHUNK_MUL 4u /* largest chunk, in units of TRACE_CHUNK: larger chunks lengthen the tail of a launch */
 #endif
+#ifndef TRACE_XCD_SUPER
+#define TRACE_XCD_SUPER 64u /* chunks per super-chunk: consecutive super-chunks go to the 8 XCDs in turn (0: one shared queue) */
+#endif
 #ifndef TRACE_MIN_CHUNKS_PER_WAVE
 #define TRACE_MIN_CHUNKS_PER_WAVE 16u /* chunks grow only while every wave still gets this many on average */
 #endif
@@ -219,19 +222,35 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
      * queues (finer balance in the tail, and the rays in flight stay close together), growing
      * to TRACE_MAX_CHUNK_MUL times that while every wave still gets TRACE_MIN_CHUNKS_PER_WAVE chunks on average, so
      * that a long queue does not saturate the atomic (one address sustains about 90 M/s).
-     * A wave's first chunk is the one with its own number; later ones come from the shared
-     * head, which therefore starts after the last wave's.  So a launch does not open with
-     * every wave queueing on one atomic, and the waves of an almost empty launch leave at once.
+     * A wave's first chunk is static (its own number in its queue, see below); later ones come
+     * from a shared head, which therefore starts after the last wave's.  So a launch does not
+     * open with every wave queueing on one atomic, and a launch that the static chunks cover
+     * (most of the deep bounces) touches no atomic at all.
      * (Measured and rejected: reading the head before bumping it, to spare the last failing
      * atomic per wave -- a device-scope load per chunk made the kernel four times slower; and
      * chunk sizes that shrink with the work left -- faster on coherent camera rays, slower on
      * everything else.) */
     const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / 64);
+#if !TRACE_XCD_SUPER
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (TRACE_BLOCK / 64) + (threadIdx.x >> 6));
+#endif
     uint32_t chunk = TRACE_CHUNK;
     while (chunk < TRACE_MAX_CHUNK_MUL * TRACE_CHUNK && (uint64_t)chunk * 2u * TRACE_MIN_CHUNKS_PER_WAVE * n_waves <= n) chunk *= 2u;
     const uint32_t total_chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
     bool first_chunk = true;              /* wave-uniform */
+#if TRACE_XCD_SUPER
+    /* Workgroups are dealt to the 8 XCDs in turn, and every XCD has its own L2.  The queue is
+     * therefore cut into super-chunks of TRACE_XCD_SUPER chunks that go to the XCDs in turn:
+     * neighbouring rays are traced on ONE XCD and share its L2 instead of pulling the same
+     * records into all eight.  Each XCD has its own queue head; an XCD that runs dry takes from
+     * the next one's.  The k-th chunk of XCD x is chunk ((k / SUPER) * 8 + x) * SUPER + k % SUPER. */
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t xcd_waves = n_waves >> 3;
+    const uint32_t xcd_wave = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * (TRACE_BLOCK / 64) + (threadIdx.x >> 6));
+    uint32_t from_xcd = xcd, tried = 0;   /* wave-uniform: whose head this wave currently takes from */
+    /* the static chunks cover every full row of 8 super-chunks that the XCD's waves span */
+    const bool static_only = total_chunks <= (xcd_waves / TRACE_XCD_SUPER) * TRACE_XCD_SUPER * 8u;
+#endif
     const bool scene_tame = root_is_tame(sc.root);
 
     /* The loop is software-pipelined: the loads a round consumes are issued during the round
@@ -345,11 +364,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
                 if (pool_next >= pool_end) {
+#if TRACE_XCD_SUPER
+                    uint32_t c = total_chunks;
+                    if (first_chunk) {
+                        c = ((xcd_wave / TRACE_XCD_SUPER) * 8u + xcd) * TRACE_XCD_SUPER + xcd_wave % TRACE_XCD_SUPER;
+                    } else if (!static_only) {
+                        while (tried < 8u) {
+                            uint32_t k = 0;
+                            if (lane == 0) k = atomicAdd(a.d_next_chunk + from_xcd * 8u, 1u);
+                            k = xcd_waves + __builtin_amdgcn_readfirstlane(k);
+                            c = ((k / TRACE_XCD_SUPER) * 8u + from_xcd) * TRACE_XCD_SUPER + k % TRACE_XCD_SUPER;
+                            if (c < total_chunks) break;
+                            from_xcd = (from_xcd + 1u) & 7u; tried++;   /* that XCD's share is used up */
+                            c = total_chunks;
+                        }
+                    }
+#else
                     uint32_t c = wave_id;
                     if (!first_chunk) {
                         if (lane == 0) c = atomicAdd(a.d_next_chunk, 1u);
                         c = n_waves + __builtin_amdgcn_readfirstlane(c);
                     }
+#endif
                     first_chunk = false;
                     if (c < total_chunks) {
                         const uint64_t first = (uint64_t)c * chunk;
@@ -417,9 +453,9 @@ struct RenderBuffers {
 #define CNT_SHADOW 12
 #define CNT_DEFER 24
 #define CNT_SAMPLES 36
-#define CNT_CHUNKS 64            /* one queue head per (kind, depth), 32 bytes apart: 64 + (kind*12 + depth)*8 */
-#define CNT_CHUNK(kind, depth) (CNT_CHUNKS + ((kind) * 12 + (depth)) * 8)
-#define CNT_WORDS (CNT_CHUNKS + 3 * 12 * 8)
+#define CNT_CHUNKS 64            /* eight queue heads (one per XCD, 32 bytes apart) per (kind, depth): 64 + (kind*12 + depth)*64 */
+#define CNT_CHUNK(kind, depth) (CNT_CHUNKS + ((kind) * 12 + (depth)) * 64)
+#define CNT_WORDS (CNT_CHUNKS + 3 * 12 * 64)
 
 __device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_sp, uint32_t p) {
     uint32_t lo = 0, hi = n_sp;
@@ -624,6 +660,11 @@ __global__ void k_film_add(float4* film, size_t n, const float* rgb, const int32
 
 struct TimedLaunch { int cls; hipEvent_t a, b; };
 
+/* layout of pt_scene::d_small: a launch's queue heads are 8 counters, 8 words apart */
+#define SMALL_HEADS0 64
+#define SMALL_HEADS1 128
+#define SMALL_WORDS 192
+
 /* Where a kernel goes: the stream, and the stack spill area that the trace launches of that
  * stream share (launches on one stream run one after another). */
 struct LaunchCtx { hipStream_t stream; uint32_t* spill; };
@@ -637,7 +678,7 @@ struct pt_scene {
     void* d_tris = nullptr;
     void* d_shade = nullptr;
     uint64_t n_tris = 0;
-    uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, [8..15] and [16..23] queue heads */
+    uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, two sets of queue heads at SMALL_HEADS0/1 */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
     /* second render lane (see pt_render_passes): its own stream and spill area, made on first use */
     hipStream_t stream2 = nullptr;
@@ -771,7 +812,7 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     size_t tb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_isect);
     size_t sb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_shade);
     if (hipMalloc(&s->d_nodes, nb) != hipSuccess || hipMalloc(&s->d_tris, tb) != hipSuccess ||
-        hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, 32 * sizeof(uint32_t)) != hipSuccess)
+        hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, SMALL_WORDS * sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(PT_ERR_DEVICE, "hipMalloc failed for the scene arrays"));
     bool ok = true;
     if (flat->n_nodes) ok = ok && hipMemcpy(s->d_nodes, flat->nodes, flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
@@ -860,8 +901,9 @@ static int init_trace_launch(pt_scene* s) {
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) { per_cu_c = v; per_cu_a = v; } }
     per_cu_c = std::max(1, std::min(per_cu_c, 8));
     per_cu_a = std::max(1, std::min(per_cu_a, 8));
-    s->grid_closest = s->num_cus * per_cu_c;
-    s->grid_any = s->num_cus * per_cu_a;
+    /* a multiple of 8: the kernels deal their queue to the 8 XCDs by workgroup number */
+    s->grid_closest = std::max(8, (s->num_cus * per_cu_c) & ~7);
+    s->grid_any = std::max(8, (s->num_cus * per_cu_a) & ~7);
     size_t threads = (size_t)std::max(s->grid_closest, s->grid_any) * TRACE_BLOCK;
     size_t words = threads * (size_t)(STACK_MAX_CLOSEST - STACK_LDS);
     s->spill_bytes = words * sizeof(uint32_t);
@@ -896,11 +938,11 @@ int pt_raycast_closest_dev(pt_scene* s, uint64_t n, const float* ox, const float
     int rc = set_device(s);
     if (rc) return rc;
     if (s->n_tris == 0) return fill_miss_closest(s, n, idx, t, u, v);
-    uint32_t init[32] = {(uint32_t)n};
+    uint32_t init[SMALL_WORDS] = {(uint32_t)n};
     HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
     TraceArgs a{};
     a.rays = {ox, oy, oz, dx, dy, dz};
-    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 8;
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + SMALL_HEADS0;
     a.out_idx = idx; a.out_t = t; a.out_u = u; a.out_v = v;
     return launch_trace<TRACE_CLOSEST_MESH>(s, a);
 }
@@ -921,16 +963,16 @@ int pt_raycast_shadow_dev(pt_scene* s, uint64_t n, const float* ox, const float*
         HIP_TRY(hipMalloc((void**)&s->d_defer, n * sizeof(uint32_t)));
         s->defer_cap = n;
     }
-    uint32_t init[32] = {(uint32_t)n};
+    uint32_t init[SMALL_WORDS] = {(uint32_t)n};
     HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
     TraceArgs a{};
     a.rays = {ox, oy, oz, dx, dy, dz};
-    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 8;
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + SMALL_HEADS0;
     a.dist = dist; a.vis = vis;
     a.defer_list = s->d_defer; a.defer_count = s->d_small + 1;
     rc = launch_trace<TRACE_SHADOW_ANY>(s, a);
     if (rc) return rc;
-    a.d_count = s->d_small + 1; a.d_next_chunk = s->d_small + 16;
+    a.d_count = s->d_small + 1; a.d_next_chunk = s->d_small + SMALL_HEADS1;
     return launch_trace<TRACE_SHADOW_EXACT>(s, a);
 }
 
@@ -943,11 +985,11 @@ int pt_raycast_occluded_dev(pt_scene* s, uint64_t n, const float* ox, const floa
     int rc = set_device(s);
     if (rc) return rc;
     if (s->n_tris == 0) { HIP_TRY(hipMemsetAsync(vis, 1, n, s->stream)); return PT_OK; }
-    uint32_t init[32] = {(uint32_t)n};
+    uint32_t init[SMALL_WORDS] = {(uint32_t)n};
     HIP_TRY(hipMemcpyAsync(s->d_small, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
     TraceArgs a{};
     a.rays = {ox, oy, oz, dx, dy, dz};
-    a.d_count = s->d_small; a.d_next_chunk = s->d_small + 8;
+    a.d_count = s->d_small; a.d_next_chunk = s->d_small + SMALL_HEADS0;
     a.dist = max_t; a.vis = vis;
     return launch_trace<TRACE_SHADOW_BOUNDED>(s, a);
 }
