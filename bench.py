@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+CU_GATHER_PEAK_GBS = 13400.0  # measured: scattered 64-byte records through the CUs' vector-memory path, L2-resident
 
 
 def parse():
@@ -242,6 +243,15 @@ def main():
                         "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
                         "rays_per_launch": round(closest / launches_c, 1),
                         "avg_launch_ms": round(ms_c / launches_c, 4),
+                        # what the kernel really loads (one 64-byte record per node visit = two box tests, 48 bytes
+                        # per triangle test, the ray) against what the CUs' load path delivers for that access shape
+                        "cu_load_path": {"achieved": round(closest / launches_c * (n_box_c * 32 + n_tri_c * 48 + 24) /
+                                                           (ms_c / launches_c * 1e-3) / 1e9, 2),
+                                         "peak": CU_GATHER_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(closest / launches_c * (n_box_c * 32 + n_tri_c * 48 + 24) /
+                                                       (ms_c / launches_c * 1e-3) / 1e9 / CU_GATHER_PEAK_GBS, 4),
+                                         "peak_source": "scripts/micro/gather_rate.hip: 64 lanes loading their own 64-byte "
+                                                        "records, L2-resident table, whole chip (profiles/r01i_micro_gather_rate.txt)"},
                         "shadow_kernel": {"algorithmic_bytes_per_ray": round(float(b_shadow), 1),
                                           "box_tests_per_ray": round(float(n_box_s), 3),
                                           "tri_tests_per_ray": round(float(n_tri_s), 3),
