@@ -483,14 +483,19 @@ __device__ __forceinline__ uint32_t block_compact(bool flag, uint32_t* counter, 
         uint32_t total = 0;
         for (uint32_t w = 0; w < NW; w++) { uint32_t t = s_wave[w]; s_wave[w] = total; total += t; }
         s_wave[NW] = total ? atomicAdd(counter, total) : 0u;
+        s_wave[NW + 1] = total;
     }
     __syncthreads();
     return s_wave[NW] + s_wave[wid] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
+/* After block_compact: the first slot the workgroup got and how many it got. */
+#define BLOCK_COMPACT_WORDS (STREAM_BLOCK / 64 + 2)
+__device__ __forceinline__ uint32_t block_compact_base(const uint32_t* s_wave) { return s_wave[STREAM_BLOCK / 64]; }
+__device__ __forceinline__ uint32_t block_compact_total(const uint32_t* s_wave) { return s_wave[STREAM_BLOCK / 64 + 1]; }
 
 __global__ __launch_bounds__(STREAM_BLOCK) void k_generate(CamParams cam, const SubPass* sp, uint32_t n_sp, uint32_t n_paths,
                                                             uint64_t seed, RenderBuffers b) {
-    __shared__ uint32_t s_wave[STREAM_BLOCK / 64 + 1];
+    __shared__ uint32_t s_wave[BLOCK_COMPACT_WORDS];
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     int px = 0, py = 0;
@@ -535,10 +540,19 @@ __global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int 
     out.dx[k] = d.x; out.dy[k] = d.y; out.dz[k] = d.z;
 }
 
-/* Hit branch of cast_ray for every ray of the current queue (cur = depth & 1). */
+/* Hit branch of cast_ray for every ray of the current queue (cur = depth & 1).
+ *
+ * Two phases per workgroup pass.  First one thread per ray: the surface frame (normal, lifted hit
+ * point, mirror direction), the bounce ray, and the frame parked in LDS under the path's place
+ * among the workgroup's hits.  Then one thread per LIGHT SAMPLE, in the order of the shadow queue
+ * (entry slot*n_lights + l): the jittered light sample and its ten words.  So the lights of a
+ * surface point are worked on by neighbouring lanes instead of a loop, and every store of the
+ * shadow queue is 64 consecutive words instead of a stride-n_lights scatter. */
+#define SHADE_FRAME_WORDS 12
 __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
                                                          uint32_t depth, int last_depth, uint64_t seed, RenderBuffers b) {
-    __shared__ uint32_t s_wave[STREAM_BLOCK / 64 + 1];
+    __shared__ uint32_t s_wave[BLOCK_COMPACT_WORDS];
+    __shared__ float s_frame[SHADE_FRAME_WORDS][STREAM_BLOCK];
     const uint32_t n = b.cnt[CNT_QUEUE + depth];
     const int cur = depth & 1, nxt = cur ^ 1;
     for (uint32_t base_i = blockIdx.x * STREAM_BLOCK; base_i < n; base_i += gridDim.x * STREAM_BLOCK) {
@@ -561,6 +575,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
         }
         /* surviving paths keep one slot in the next queue and n_lights slots in the shadow queue */
         const uint32_t slot = block_compact(hit, &b.cnt[CNT_QUEUE + depth + 1], s_wave);
+        const uint32_t slot0 = block_compact_base(s_wave), n_hit = block_compact_total(s_wave);
         if (hit) {
             const float4* sp = sc.shade + (size_t)tri * 4;
             float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
@@ -573,14 +588,11 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             SurfaceFrame f = surface_frame(o, d, hrec.y, hrec.z, hrec.w, st);
             float thr = b.thr[path];
             uint32_t pixel = b.pixel[path], sample = b.sample[path];
-            for (uint32_t l = 0; l < n_lights; l++) {
-                LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
-                uint32_t j = slot * n_lights + l;
-                b.sh.ox[j] = f.hit.x; b.sh.oy[j] = f.hit.y; b.sh.oz[j] = f.hit.z;
-                b.sh.dx[j] = ls.dir.x; b.sh.dy[j] = ls.dir.y; b.sh.dz[j] = ls.dir.z;
-                b.sh_dist[j] = ls.dist;
-                b.sh_wr[j] = thr * ls.weight.x; b.sh_wg[j] = thr * ls.weight.y; b.sh_wb[j] = thr * ls.weight.z;
-            }
+            const uint32_t k = slot - slot0;
+            s_frame[0][k] = f.n.x; s_frame[1][k] = f.n.y; s_frame[2][k] = f.n.z;
+            s_frame[3][k] = f.hit.x; s_frame[4][k] = f.hit.y; s_frame[5][k] = f.hit.z;
+            s_frame[6][k] = f.refl.x; s_frame[7][k] = f.refl.y; s_frame[8][k] = f.refl.z;
+            s_frame[9][k] = thr; s_frame[10][k] = __uint_as_float(pixel); s_frame[11][k] = __uint_as_float(sample);
             b.qpath[nxt][slot] = path;
             if (!last_depth) {
                 V3f bo, bd;
@@ -591,6 +603,25 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
                 b.thr[path] = 0.8f * thr; /* reference integrator.cpp:107 */
             }
         }
+        __syncthreads();
+        /* one thread per light sample of the workgroup's hits, in shadow-queue order */
+        const uint32_t n_samples = n_hit * n_lights;
+        for (uint32_t j = threadIdx.x; j < n_samples; j += STREAM_BLOCK) {
+            const uint32_t k = j / n_lights, l = j - k * n_lights;
+            SurfaceFrame f;
+            f.n = v3(s_frame[0][k], s_frame[1][k], s_frame[2][k]);
+            f.hit = v3(s_frame[3][k], s_frame[4][k], s_frame[5][k]);
+            f.refl = v3(s_frame[6][k], s_frame[7][k], s_frame[8][k]);
+            const float thr = s_frame[9][k];
+            const uint32_t pixel = __float_as_uint(s_frame[10][k]), sample = __float_as_uint(s_frame[11][k]);
+            LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
+            const size_t q = (size_t)slot0 * n_lights + j;
+            b.sh.ox[q] = f.hit.x; b.sh.oy[q] = f.hit.y; b.sh.oz[q] = f.hit.z;
+            b.sh.dx[q] = ls.dir.x; b.sh.dy[q] = ls.dir.y; b.sh.dz[q] = ls.dir.z;
+            b.sh_dist[q] = ls.dist;
+            b.sh_wr[q] = thr * ls.weight.x; b.sh_wg[q] = thr * ls.weight.y; b.sh_wb[q] = thr * ls.weight.z;
+        }
+        /* the next pass's block_compact begins with a barrier, which also protects s_frame */
     }
 }
 
