@@ -125,3 +125,30 @@ def test_films_reduce_arguments(scene_tiny):
     two = (C.c_void_p * 2)(a.h, b.h)
     assert L.pt_films_reduce(two, 2, rgb.ctypes.data, passes.ctypes.data) == -1
     assert b"one GPU" in L.pt_last_error()
+
+
+def test_light_counts_one_to_sixteen(scene_small):
+    """PT_MAX_LIGHTS = 16 is the most a render call takes; 17 is refused.  One light and sixteen
+    lights (with a sky colour, so that paths that leave the scene also count) against the oracle."""
+    sc = scene_small
+    W, H, S = 64, 40, 2
+    rng = np.random.default_rng(21)
+    many = [((float(3 * np.cos(k)), float(3 * np.sin(k)), float(1.5 + 0.2 * k)), tuple(float(x) for x in rng.random(3) * 4))
+            for k in range(16)]
+    film = pta.Film(sc.gpu, W, H)
+    for lights in (many[:1], many):
+        cam_o = orc.cli_camera(dof_aperture=0.05, dof_distance=4.5)
+        cam_g = pta.cli_camera(dof_aperture=0.05, dof_distance=4.5)
+        cam_o.sky_color[:] = [0.1, 0.2, 0.3]
+        cam_g.sky_color[:] = [0.1, 0.2, 0.3]
+        want_rgb, want_p, want_counts = sc.oracle.render(cam_o, lights, W, H, None, 0, S, seed=9)
+        film.zero()
+        st = film.render(cam_g, lights, [(0, 0, -1, -1, 0, S)], seed=9)
+        rgb, passes = film.read()
+        assert np.array_equal(passes, want_p)
+        assert st.closest_rays == int(want_counts[0]) and st.shadow_rays == int(want_counts[1])
+        assert st.shadow_rays % len(lights) == 0
+        err = np.abs(rgb - want_rgb)
+        assert (err <= 2e-5 * np.maximum(np.abs(want_rgb), 1.0)).all(), (len(lights), err.max())
+    with pytest.raises(RuntimeError):
+        film.render(pta.cli_camera(), many + many[:1], [(0, 0, -1, -1, 0, 1)], seed=9)
