@@ -152,3 +152,25 @@ def test_light_counts_one_to_sixteen(scene_small):
         assert (err <= 2e-5 * np.maximum(np.abs(want_rgb), 1.0)).all(), (len(lights), err.max())
     with pytest.raises(RuntimeError):
         film.render(pta.cli_camera(), many + many[:1], [(0, 0, -1, -1, 0, 1)], seed=9)
+
+
+def test_overlapping_rectangles_in_one_call(scene_small):
+    """Different rectangles that overlap cannot share a batch (their film updates would race);
+    the call cuts the batch there.  Pass counts add up where they overlap, radiance matches the
+    oracle's accumulation of the same passes in the same order."""
+    sc = scene_small
+    W, H = 72, 48
+    passes_list = [(0, 0, 40, 30, 0, 2), (20, 10, 40, 30, 2, 1), (0, 0, 40, 30, 3, 1), (30, 20, -1, -1, 4, 2), (20, 10, 40, 30, 6, 1)]
+    film = pta.Film(sc.gpu, W, H)
+    st = film.render(pta.cli_camera(), pta.cli_lights(), passes_list, seed=13)
+    rgb, passes = film.read()
+    want_rgb = np.zeros((H, W, 3), np.float32)
+    want_p = np.zeros((H, W), np.int32)
+    total = np.zeros(2, np.int64)
+    for (x, y, w, h, first, n) in passes_list:
+        _, _, c = sc.oracle.render(orc.cli_camera(), orc.cli_lights(), W, H, (x, y, w, h), first, n, seed=13, rgb=want_rgb, passes=want_p)
+        total += np.asarray(c[:2], np.int64)
+    assert np.array_equal(passes, want_p) and passes.max() == 7
+    assert st.closest_rays == int(total[0]) and st.shadow_rays == int(total[1])
+    err = np.abs(rgb - want_rgb)
+    assert (err <= 2e-5 * np.maximum(np.abs(want_rgb), 1.0)).all(), err.max()
