@@ -126,11 +126,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    closest = shadow = samples = 0
+    closest = shadow = samples = traced = 0
     for i in range(args.warmup, total_steps):
         st = step(i)
         closest += st.closest_rays
         shadow += st.shadow_rays
+        traced += st.shadow_rays_traced
         samples += st.camera_samples
     gpu.sync()
     reduce_film(film_t, dst=0)  # Canvas::add_from over all workers: one RCCL reduce when world > 1
@@ -140,12 +141,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
 
-    tot = torch.tensor([float(closest), float(shadow), float(samples)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(closest), float(shadow), float(samples), float(traced)], dtype=torch.float64, device="cuda")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    closest_all, shadow_all, samples_all = [float(x) for x in tot.cpu()]
+    closest_all, shadow_all, samples_all, traced_all = [float(x) for x in tot.cpu()]
     elapsed = float(tmax.cpu()[0])
 
     kt = {c: gpu.kernel_time(c) for c in range(5)}
@@ -176,6 +177,10 @@ def main():
             "wall_s_1080p_1000spp_extrapolated": round(elapsed / samples_all * 1920 * 1080 * 1000, 2),
             "rays_per_sample": round(rays_all / samples_all, 4),
             "closest_rays": int(closest_all), "shadow_rays": int(shadow_all), "camera_samples": int(samples_all),
+            # rays are counted as the reference casts them; a shadow ray whose light sample has zero weight
+            # cannot change the picture and is counted but not traced
+            "shadow_rays_traced": int(traced_all),
+            "traced_Mrays_per_s": round((closest_all + traced_all) / elapsed / 1e6, 2),
             "film_check": film_ok,
             "scene_prepare_s": round(t_prepare, 2),
             "kernel_ms": {name: {"ms": round(kt[c][0], 3), "launches": kt[c][1]} for c, name in
@@ -255,7 +260,8 @@ def main():
                         "shadow_kernel": {"algorithmic_bytes_per_ray": round(float(b_shadow), 1),
                                           "box_tests_per_ray": round(float(n_box_s), 3),
                                           "tri_tests_per_ray": round(float(n_tri_s), 3),
-                                          "achieved": round(shadow / max(kt[1][1], 1) * b_shadow /
+                                          "rays_traced": int(traced),
+                                          "achieved": round(traced / max(kt[1][1], 1) * b_shadow /
                                                             (kt[1][0] / max(kt[1][1], 1) * 1e-3) / 1e9, 2) if kt[1][0] > 0 else None}}
         out["roofline"] = roof
         out["cpu_baseline"] = cpu

@@ -204,6 +204,10 @@ typedef struct pt_render_stats {
     uint64_t closest_rays;       /* what `rays_cast++` (kdtree.cpp:578) would count from :57  */
     uint64_t shadow_rays;        /* ... and from integrator.cpp:127                            */
     double   gpu_ms;             /* GPU time of this call, HIP events on the scene's stream    */
+    uint64_t shadow_rays_traced; /* of shadow_rays, those actually traced: a light sample whose
+                                    weight (integrator.cpp:131-145) is exactly zero adds nothing
+                                    whether the light is visible or not, so its ray is counted
+                                    (the reference casts it) but not traced                     */
 } pt_render_stats;
 
 typedef struct pt_film pt_film;

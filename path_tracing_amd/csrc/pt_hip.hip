@@ -175,6 +175,7 @@ struct TraceArgs {
                                 retiring lane issues one store instead of four partial-line writes */
     const float* dist;       /* shadow modes */
     uint8_t* vis;            /* shadow modes */
+    const uint32_t* target;  /* shadow modes, optional: ray i answers into vis[target[i]] instead of vis[i] */
     uint32_t* defer_list;    /* SHADOW_ANY appends ray indices here, SHADOW_EXACT reads them */
     uint32_t* defer_count;   /* SHADOW_ANY: atomic length of defer_list (zero at launch) */
     uint32_t* spill;         /* stack spill area: (STACK_MAX - STACK_LDS) * threads-in-grid dwords */
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
     Lane L;
     L.cur = PT_REF_NONE; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
     int32_t ray = -1;         /* index of the ray this lane is tracing, or -1 (idle) */
+    uint32_t tgt = 0;         /* shadow modes: where this ray's answer goes (loaded with the ray) */
     float dist = 0.0f;
     uint32_t pool_next = 0, pool_end = 0; /* wave-uniform: unclaimed rays of the current chunk */
     bool exhausted = false;               /* wave-uniform: the queue has no more chunks */
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
          * along every control path and nothing below waits on global memory again. */
         asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
                            "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
-        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist));
+        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist), "v"(tgt));
 
         /* ---- start the refilled lanes (they take their first record with everyone else below) ---- */
         bool defer = false;
@@ -350,9 +352,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
                     a.out_v[i] = L.found ? L.best.v : 0.0f;
                 }
             } else if (ANY) {
-                a.vis[i] = L.found ? 0 : 1;
+                a.vis[a.target ? tgt : i] = L.found ? 0 : 1;
             } else {
-                a.vis[i] = (!L.found || L.best.v > dist) ? 1 : 0;
+                a.vis[a.target ? tgt : i] = (!L.found || L.best.v > dist) ? 1 : 0;
             }
             ray = -1;
         }
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
          * into them. */
         if (starting) {
             if (MODE == TRACE_SHADOW_EXACT) new_ray = a.defer_list[new_ray];
-            if (!CLOSEST_OUT) dist = a.dist[new_ray];
+            if (!CLOSEST_OUT) { dist = a.dist[new_ray]; if (a.target) tgt = a.target[new_ray]; }
             L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
             L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
         }
@@ -442,20 +444,24 @@ struct RenderBuffers {
     /* per light sample of the current depth: slot*n_lights + l */
     RaySoAW sh;
     float *sh_dist, *sh_wr, *sh_wg, *sh_wb;
-    uint8_t* sh_vis;
+    uint8_t* sh_vis;      /* per light sample (entry slot*n_lights + l), like the weights */
+    uint32_t* sh_target;  /* per traced shadow ray: the light-sample entry it answers for */
     uint32_t* sh_defer;
-    /* counters: [0..11] queue length per depth, [12..23] shadow-ray count per depth,
-     * [24..35] shadow rays per depth that need the exact pass, [36] camera samples,
-     * [64..] the queue head of every trace launch of the batch */
+    /* counters: [0..11] queue length per depth, [24..35] shadow rays per depth that need the
+     * exact pass, [36] camera samples, [64..] the queue heads of every trace launch of the batch,
+     * then the number of traced shadow rays per depth, each in a cache line of its own (k_shade
+     * bumps it and the next queue's length from every workgroup: on one line the two would queue
+     * behind each other) */
     uint32_t* cnt;
 };
 #define CNT_QUEUE 0
-#define CNT_SHADOW 12
 #define CNT_DEFER 24
 #define CNT_SAMPLES 36
 #define CNT_CHUNKS 64            /* eight queue heads (one per XCD, 32 bytes apart) per (kind, depth): 64 + (kind*12 + depth)*64 */
 #define CNT_CHUNK(kind, depth) (CNT_CHUNKS + ((kind) * 12 + (depth)) * 64)
-#define CNT_WORDS (CNT_CHUNKS + 3 * 12 * 64)
+#define CNT_SHADOW_BASE (CNT_CHUNKS + 3 * 12 * 64)
+#define CNT_SHADOW(depth) (CNT_SHADOW_BASE + (depth) * 32)
+#define CNT_WORDS (CNT_SHADOW_BASE + 12 * 32)
 
 __device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_sp, uint32_t p) {
     uint32_t lo = 0, hi = n_sp;
@@ -549,10 +555,13 @@ __global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int 
  * surface point are worked on by neighbouring lanes instead of a loop, and every store of the
  * shadow queue is 64 consecutive words instead of a stride-n_lights scatter. */
 #define SHADE_FRAME_WORDS 12
+#define SHADE_GROUP 3   /* light samples per thread between two compactions of the shadow-ray queue */
 __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
                                                          uint32_t depth, int last_depth, uint64_t seed, RenderBuffers b) {
     __shared__ uint32_t s_wave[BLOCK_COMPACT_WORDS];
     __shared__ float s_frame[SHADE_FRAME_WORDS][STREAM_BLOCK];
+    __shared__ uint32_t s_group[SHADE_GROUP][STREAM_BLOCK / 64];
+    __shared__ uint32_t s_group_base;
     const uint32_t n = b.cnt[CNT_QUEUE + depth];
     const int cur = depth & 1, nxt = cur ^ 1;
     for (uint32_t base_i = blockIdx.x * STREAM_BLOCK; base_i < n; base_i += gridDim.x * STREAM_BLOCK) {
@@ -604,22 +613,65 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             }
         }
         __syncthreads();
-        /* one thread per light sample of the workgroup's hits, in shadow-queue order */
+        /* One thread per light sample of the workgroup's hits, in the order of the samples'
+         * entries (slot*n_lights + l).  The weight goes to the sample's entry.  The shadow ray goes
+         * to the ray queue only if the weight is not exactly zero: a zero weight (light behind the
+         * surface for both the Lambert and the mirror term, or a black light) adds nothing whether
+         * the light is visible or not, so that ray's answer cannot change the picture. */
         const uint32_t n_samples = n_hit * n_lights;
-        for (uint32_t j = threadIdx.x; j < n_samples; j += STREAM_BLOCK) {
-            const uint32_t k = j / n_lights, l = j - k * n_lights;
-            SurfaceFrame f;
-            f.n = v3(s_frame[0][k], s_frame[1][k], s_frame[2][k]);
-            f.hit = v3(s_frame[3][k], s_frame[4][k], s_frame[5][k]);
-            f.refl = v3(s_frame[6][k], s_frame[7][k], s_frame[8][k]);
-            const float thr = s_frame[9][k];
-            const uint32_t pixel = __float_as_uint(s_frame[10][k]), sample = __float_as_uint(s_frame[11][k]);
-            LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
-            const size_t q = (size_t)slot0 * n_lights + j;
-            b.sh.ox[q] = f.hit.x; b.sh.oy[q] = f.hit.y; b.sh.oz[q] = f.hit.z;
-            b.sh.dx[q] = ls.dir.x; b.sh.dy[q] = ls.dir.y; b.sh.dz[q] = ls.dir.z;
-            b.sh_dist[q] = ls.dist;
-            b.sh_wr[q] = thr * ls.weight.x; b.sh_wg[q] = thr * ls.weight.y; b.sh_wb[q] = thr * ls.weight.z;
+        /* SHADE_GROUP samples per thread and compaction: one atomic on the ray count per
+         * workgroup and group (one per sample row would make the counter the bottleneck: a
+         * single address takes about 90 M atomics per second) */
+        for (uint32_t j0 = 0; j0 < n_samples; j0 += SHADE_GROUP * STREAM_BLOCK) { /* same trip count for every thread */
+            bool trace[SHADE_GROUP];
+            V3f origin[SHADE_GROUP], dir[SHADE_GROUP];
+            float dist[SHADE_GROUP];
+            uint32_t off[SHADE_GROUP];
+#pragma unroll
+            for (int g = 0; g < SHADE_GROUP; g++) {
+                const uint32_t j = j0 + (uint32_t)g * STREAM_BLOCK + threadIdx.x;
+                trace[g] = false;
+                origin[g] = v3(0.0f, 0.0f, 0.0f); dir[g] = origin[g]; dist[g] = 0.0f;
+                if (j < n_samples) {
+                    const uint32_t k = j / n_lights, l = j - k * n_lights;
+                    SurfaceFrame f;
+                    f.n = v3(s_frame[0][k], s_frame[1][k], s_frame[2][k]);
+                    f.hit = v3(s_frame[3][k], s_frame[4][k], s_frame[5][k]);
+                    f.refl = v3(s_frame[6][k], s_frame[7][k], s_frame[8][k]);
+                    const float thr = s_frame[9][k];
+                    const uint32_t pixel = __float_as_uint(s_frame[10][k]), sample = __float_as_uint(s_frame[11][k]);
+                    LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
+                    const float wr = thr * ls.weight.x, wg = thr * ls.weight.y, wb = thr * ls.weight.z;
+                    const size_t q = (size_t)slot0 * n_lights + j;
+                    b.sh_wr[q] = wr; b.sh_wg[q] = wg; b.sh_wb[q] = wb;
+                    trace[g] = !(wr == 0.0f && wg == 0.0f && wb == 0.0f); /* NaN weights are traced */
+                    if (!trace[g]) b.sh_vis[q] = 0;
+                    origin[g] = f.hit; dir[g] = ls.dir; dist[g] = ls.dist;
+                }
+                const uint64_t m = __ballot(trace[g]);
+                off[g] = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                if ((threadIdx.x & 63u) == 0) s_group[g][threadIdx.x >> 6] = (uint32_t)__popcll(m);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+                for (int g = 0; g < SHADE_GROUP; g++)
+                    for (uint32_t w = 0; w < STREAM_BLOCK / 64; w++) { uint32_t t = s_group[g][w]; s_group[g][w] = total; total += t; }
+                s_group_base = total ? atomicAdd(&b.cnt[CNT_SHADOW(depth)], total) : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < SHADE_GROUP; g++) {
+                if (trace[g]) {
+                    const uint32_t r = s_group_base + s_group[g][threadIdx.x >> 6] + off[g];
+                    const uint32_t j = j0 + (uint32_t)g * STREAM_BLOCK + threadIdx.x;
+                    b.sh.ox[r] = origin[g].x; b.sh.oy[r] = origin[g].y; b.sh.oz[r] = origin[g].z;
+                    b.sh.dx[r] = dir[g].x; b.sh.dy[r] = dir[g].y; b.sh.dz[r] = dir[g].z;
+                    b.sh_dist[r] = dist[g];
+                    b.sh_target[r] = (uint32_t)((size_t)slot0 * n_lights + j);
+                }
+            }
+            __syncthreads(); /* s_group is rewritten by the next group */
         }
         /* the next pass's block_compact begins with a barrier, which also protects s_frame */
     }
@@ -1192,6 +1244,7 @@ static int lane_ensure_scratch(RenderLane* f, size_t paths, uint32_t n_lights, s
     float** per_sh[11] = {&b.sh.ox, &b.sh.oy, &b.sh.oz, &b.sh.dx, &b.sh.dy, &b.sh.dz, &b.sh_dist, &b.sh_wr, &b.sh_wg, &b.sh_wb, nullptr};
     for (int c = 0; per_sh[c] && !rc; c++) rc = film_alloc(f, per_sh[c], S);
     if (!rc) rc = film_alloc(f, &b.sh_vis, S);
+    if (!rc) rc = film_alloc(f, &b.sh_target, S);
     if (!rc) rc = film_alloc(f, &b.sh_defer, S);
     if (!rc) rc = film_alloc(f, &b.cnt, (size_t)CNT_WORDS);
     if (!rc) rc = film_alloc(f, &f->d_lights, (size_t)PT_MAX_LIGHTS);
@@ -1263,8 +1316,9 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
         if (n_lights > 0) {
             TraceArgs sa{};
             sa.rays = {b.sh.ox, b.sh.oy, b.sh.oz, b.sh.dx, b.sh.dy, b.sh.dz};
-            sa.d_count = b.cnt + CNT_QUEUE + depth + 1; /* one shadow ray per surviving path and light */
-            sa.count_mul = n_lights;
+            sa.d_count = b.cnt + CNT_SHADOW(depth); /* the light samples of this depth whose weight is not zero */
+            sa.count_mul = 1;
+            sa.target = b.sh_target;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
             sa.dist = b.sh_dist; sa.vis = b.sh_vis;
             if (cam.shadow_mode == PT_SHADOW_BOUNDED) {
@@ -1507,7 +1561,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     }
     /* Paths in flight: as many as allowed (a trace launch pays a fixed ramp-up and tail, the
      * latency of its longest rays, so longer queues run closer to the kernels' asymptotic rate:
-     * 32 -> 128 spp of 1080p per call is +13 %), but the scratch (96 bytes per path + 45 per
+     * 32 -> 128 spp of 1080p per call is +13 %), but the scratch (96 bytes per path + 49 per
      * shadow ray) stays within half of the GPU's memory and a batch's shadow rays within what one
      * trace launch accepts. */
     size_t limit = batch_paths_limit();
@@ -1515,7 +1569,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         const size_t L = (size_t)std::max(n_lights, 1);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        limit = std::min(limit, (total_b / 2) / (96 + 45 * L));
+        limit = std::min(limit, (total_b / 2) / (96 + 49 * L));
         limit = std::max<size_t>(limit, 4096);
     }
     /* With two lanes the call's paths go out as (at least) two batches that run on two streams
@@ -1540,7 +1594,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         HIP_TRY(hipEventRecord(s->ev_order, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_order, 0));
     }
-    uint64_t counts[3] = {0, 0, 0};
+    uint64_t counts[4] = {0, 0, 0, 0};
     DLight hl[PT_MAX_LIGHTS];
     for (int l = 0; l < n_lights; l++) {
         hl[l].pos = v3(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
@@ -1554,7 +1608,11 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         HIP_TRY(hipStreamSynchronize(ctx[li].stream));
         const uint32_t* h = ln.h_cnt;
         counts[0] += h[CNT_QUEUE + 0];
-        for (int d = 0; d <= 10; d++) { counts[1] += h[CNT_QUEUE + d]; counts[2] += (uint64_t)h[CNT_QUEUE + d + 1] * ln.flight_lights; }
+        for (int d = 0; d <= 10; d++) {
+            counts[1] += h[CNT_QUEUE + d];
+            counts[2] += (uint64_t)h[CNT_QUEUE + d + 1] * ln.flight_lights;
+            if (ln.flight_lights) counts[3] += h[CNT_SHADOW(d)];
+        }
         return PT_OK;
     };
     /* whatever happens, nothing of this call is in flight when it returns: the lanes' copies
@@ -1622,6 +1680,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
         stats->camera_samples = counts[0]; stats->closest_rays = counts[1]; stats->shadow_rays = counts[2];
+        stats->shadow_rays_traced = counts[3];
         stats->gpu_ms = ms;
     }
     return PT_OK;

@@ -62,7 +62,7 @@ class TilePass(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
-                ("gpu_ms", C.c_double)]
+                ("gpu_ms", C.c_double), ("shadow_rays_traced", C.c_uint64)]
 
 
 _host = None
