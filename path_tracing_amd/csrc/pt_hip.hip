@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int 
 #define SHADE_FRAME_WORDS 12
 #define SHADE_GROUP 3   /* light samples per thread between two compactions of the shadow-ray queue */
 __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
-                                                         uint32_t depth, int last_depth, uint64_t seed, RenderBuffers b) {
+                                                         uint32_t depth, int last_depth, int trace_all, uint64_t seed, RenderBuffers b) {
     __shared__ uint32_t s_wave[BLOCK_COMPACT_WORDS];
     __shared__ float s_frame[SHADE_FRAME_WORDS][STREAM_BLOCK];
     __shared__ uint32_t s_group[SHADE_GROUP][STREAM_BLOCK / 64];
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
                     const float wr = thr * ls.weight.x, wg = thr * ls.weight.y, wb = thr * ls.weight.z;
                     const size_t q = (size_t)slot0 * n_lights + j;
                     b.sh_wr[q] = wr; b.sh_wg[q] = wg; b.sh_wb[q] = wb;
-                    trace[g] = !(wr == 0.0f && wg == 0.0f && wb == 0.0f); /* NaN weights are traced */
+                    trace[g] = trace_all || !(wr == 0.0f && wg == 0.0f && wb == 0.0f); /* NaN weights are traced */
                     if (!trace[g]) b.sh_vis[q] = 0;
                     origin[g] = f.hit; dir[g] = ls.dir; dist[g] = ls.dist;
                 }
@@ -1298,6 +1298,9 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
     }
     const int light_grid = s->num_cus * 8;
     const int shade_grid = s->num_cus * 4;
+    /* PT_TRACE_ALL_SHADOW=1: trace the shadow rays of zero-weight light samples too (same picture; for checks) */
+    const char* all_env = getenv("PT_TRACE_ALL_SHADOW");
+    const int trace_all = (all_env && atoi(all_env) != 0) ? 1 : 0;
     for (uint32_t depth = 0; depth <= 10; depth++) { /* cast_ray(ray, 10, 1): recursions 10..0 */
         const int cur = depth & 1;
         TraceArgs a{};
@@ -1310,7 +1313,7 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
         {
             ScopedTimer tm(s, PT_KERNEL_SHADE, st);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, st, s->d, cam, ln.d_lights, n_lights, depth,
-                               depth == 10 ? 1 : 0, seed, b);
+                               depth == 10 ? 1 : 0, trace_all, seed, b);
             HIP_TRY(hipGetLastError());
         }
         if (n_lights > 0) {

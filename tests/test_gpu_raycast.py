@@ -226,3 +226,24 @@ def test_bounded_shadow_render_matches_oracle(scene_small):
     assert np.abs(ref_rgb - rgb).max() > 1e-2
     with pytest.raises(RuntimeError):
         film.render(pta.cli_camera(shadow_mode=2), pta.cli_lights(), [(0, 0, -1, -1, 0, 1)], seed=8)
+
+
+def test_zero_weight_shadow_rays_are_counted_not_traced(scene_small, monkeypatch):
+    """A light sample whose weight is exactly zero adds nothing whether its light is visible or
+    not, so its shadow ray is counted (the reference casts it) but not traced.  With
+    PT_TRACE_ALL_SHADOW=1 every shadow ray is traced: same film bit for bit, same reference counts."""
+    sc = scene_small
+    W, H, S = 128, 96, 3
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    film = pta.Film(sc.gpu, W, H)
+    monkeypatch.setenv("PT_TRACE_ALL_SHADOW", "1")
+    st_all = film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=17)
+    rgb_all, p_all = film.read()
+    film.zero()
+    monkeypatch.delenv("PT_TRACE_ALL_SHADOW")
+    st = film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=17)
+    rgb, p = film.read()
+    assert np.array_equal(rgb.view(np.uint32), rgb_all.view(np.uint32)) and np.array_equal(p, p_all)
+    assert (st.closest_rays, st.shadow_rays) == (st_all.closest_rays, st_all.shadow_rays)
+    assert st_all.shadow_rays_traced == st_all.shadow_rays
+    assert 0 < st.shadow_rays_traced < st.shadow_rays
