@@ -36,7 +36,8 @@ def main():
     steps_total = line["steps"] + line["warmup"]
     out = {"source": os.path.basename(root.rstrip("/")), "bench_line": {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}}
     for name, kernel, key in (("closest", "k_trace<1>", "closest_rays"), ("shadow", "k_trace<2>", "shadow_rays")):
-        rays = line[key] / line["steps"] * steps_total
+        # shadow rays: the traced ones (zero-weight light samples are counted but not traced)
+        rays = line.get(key + "_traced", line[key]) / line["steps"] * steps_total
         fetch_kb, nd = counter_sum(root, "FETCH_SIZE", kernel)
         write_kb, _ = counter_sum(root, "WRITE_SIZE", kernel)
         hit, _ = counter_sum(root, "TCC_HIT_sum", kernel)
