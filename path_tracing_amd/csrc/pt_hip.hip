@@ -80,7 +80,7 @@ struct RaySoAW {
 #define TRACE_CHUNK 64     /* fewest rays a wave takes from the queue per atomic */
 #endif
 #ifndef TRACE_MAX_CHUNK_MUL
-#define TRACE_MAX_CHUNK_MUL 4u /* largest chunk, in units of TRACE_CHUNK: larger chunks lengthen the tail of a launch */
+#define TRACE_MAX_CHUNK_MUL 2u /* largest chunk, in units of TRACE_CHUNK: larger chunks lengthen the tail of a launch */
 #endif
 #ifndef TRACE_XCD_SUPER
 #define TRACE_XCD_SUPER 64u /* chunks per super-chunk: consecutive super-chunks go to the 8 XCDs in turn (0: one shared queue) */
@@ -88,8 +88,15 @@ struct RaySoAW {
 #ifndef TRACE_MIN_CHUNKS_PER_WAVE
 #define TRACE_MIN_CHUNKS_PER_WAVE 16u /* chunks grow only while every wave still gets this many on average */
 #endif
-#ifndef REFILL_MIN
-#define REFILL_MIN 8       /* idle lanes that trigger a refill while the wave still has work */
+/* Idle lanes that trigger a refill while the wave still has work.  A refill costs seven ray loads
+ * and the start of the new rays however few lanes take part, so it pays to wait for more of them
+ * (measured on the full render, 8 / 16 / 24 / 32 / 48: closest hit 160 / 155 / 157 / 164 / 161 ms,
+ * any hit 176 / 161 / 154 / 153 / 169 ms). */
+#ifndef REFILL_MIN_CLOSEST
+#define REFILL_MIN_CLOSEST 16
+#endif
+#ifndef REFILL_MIN_ANY
+#define REFILL_MIN_ANY 32
 #endif
 #ifndef TRACE_WAVES_PER_EU
 #define TRACE_WAVES_PER_EU 6 /* register budget of the trace kernels: waves per SIMD the compiler must allow */
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         starting = false;
         if (idle) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (!exhausted && (n_idle >= REFILL_MIN || idle == ~0ull)) {
+            if (!exhausted && (n_idle >= (ANY ? REFILL_MIN_ANY : REFILL_MIN_CLOSEST) || idle == ~0ull)) {
                 if (pool_next >= pool_end) {
 #if TRACE_XCD_SUPER
                     uint32_t c = total_chunks;
