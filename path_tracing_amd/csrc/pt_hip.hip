@@ -85,6 +85,13 @@ struct RaySoAW {
 #ifndef TRACE_XCD_SUPER
 #define TRACE_XCD_SUPER 64u /* chunks per super-chunk: consecutive super-chunks go to the 8 XCDs in turn (0: one shared queue) */
 #endif
+#ifndef TRACE_MAX_POPS
+#define TRACE_MAX_POPS 1   /* stack pops a lane may take in one round before it has to wait for the next
+                              (1 / 2 / 3 on the full render: 6 360 / 6 280 / 6 170 Mrays/s) */
+#endif
+#ifndef SHADE_GRID_MUL
+#define SHADE_GRID_MUL 8   /* workgroups per CU of the shade kernel's grid (2 / 4 / 8 / 16: 33.7 / 33.2 / 30.6 / 29.6 ms) */
+#endif
 #ifndef TRACE_MIN_CHUNKS_PER_WAVE
 #define TRACE_MIN_CHUNKS_PER_WAVE 16u /* chunks grow only while every wave still gets this many on average */
 #endif
@@ -99,7 +106,8 @@ struct RaySoAW {
 #define REFILL_MIN_ANY 32
 #endif
 #ifndef TRACE_WAVES_PER_EU
-#define TRACE_WAVES_PER_EU 6 /* register budget of the trace kernels: waves per SIMD the compiler must allow */
+#define TRACE_WAVES_PER_EU 8 /* register budget of the trace kernels: waves per SIMD the compiler must allow
+                                (6 -> 8: the same 56-57 registers, but a schedule that is 2 % faster) */
 #endif
 
 /* Per-lane stack.  The first STACK_LDS entries live in LDS, dword-interleaved across the block
@@ -330,7 +338,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         /* ---- lanes left with neither a leaf nor a node take their next one from the stack ---- */
         if (active && L.cur == PT_REF_NONE && L.sp > 0) {
             lane_pop<ANY>(L, st);
+#if TRACE_MAX_POPS >= 2
             if (L.cur == PT_REF_NONE && L.sp > 0) lane_pop<ANY>(L, st);
+#endif
+#if TRACE_MAX_POPS >= 3
+            if (L.cur == PT_REF_NONE && L.sp > 0) lane_pop<ANY>(L, st);
+#endif
         }
         /* ---- next round's records (one load site: a second one for the lanes that know their
          * record before the pops would make the compiler wait for the first, since both target
@@ -1304,7 +1317,7 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
         HIP_TRY(hipGetLastError());
     }
     const int light_grid = s->num_cus * 8;
-    const int shade_grid = s->num_cus * 4;
+    const int shade_grid = s->num_cus * SHADE_GRID_MUL;
     /* PT_TRACE_ALL_SHADOW=1: trace the shadow rays of zero-weight light samples too (same picture; for checks) */
     const char* all_env = getenv("PT_TRACE_ALL_SHADOW");
     const int trace_all = (all_env && atoi(all_env) != 0) ? 1 : 0;
