@@ -199,8 +199,8 @@ struct TraceArgs {
 /*
  * Persistent trace kernel.  Every wave loops over "rounds"; in a round each lane that holds a
  * ray advances it by one step of the lane state machine (traverse_core.h): one triangle of its
- * pending leaf, or one interior node, followed by stack pops until it has a leaf or a node
- * again (at most two per round).
+ * pending leaf, or one interior node, followed by stack pops while it has neither a leaf nor a
+ * node (at most TRACE_MAX_POPS per round).
  *
  * A round consumes ONE group of global loads, all in flight before any is used, so it costs one
  * memory round trip:
