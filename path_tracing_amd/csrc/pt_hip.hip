@@ -463,8 +463,12 @@ struct RenderBuffers {
     float *rad_r, *rad_g, *rad_b, *thr;
     /* per light sample of the current depth: slot*n_lights + l */
     RaySoAW sh;
-    float *sh_dist, *sh_wr, *sh_wg, *sh_wb;
-    uint8_t* sh_vis;      /* per light sample (entry slot*n_lights + l), like the weights */
+    float* sh_dist;
+    /* per light sample (entry slot*n_lights + l): what it adds if its light is visible, and whether
+     * it is.  Two sets, used by even and odd depths in turn: the samples of depth d are added to
+     * their paths by k_shade of depth d+1, which is writing the samples of depth d+1 meanwhile. */
+    float *sh_wr[2], *sh_wg[2], *sh_wb[2];
+    uint8_t* sh_vis[2];
     uint32_t* sh_target;  /* per traced shadow ray: the light-sample entry it answers for */
     uint32_t* sh_defer;
     /* counters: [0..11] queue length per depth, [24..35] shadow rays per depth that need the
@@ -595,11 +599,24 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             hrec = b.hit[i];
             tri = (int32_t)__float_as_uint(hrec.x);
             hit = tri >= 0;
-            if (!hit) { /* sky, reference integrator.cpp:153 */
-                float thr = b.thr[path];
-                if (cam.sky.x != 0.0f || cam.sky.y != 0.0f || cam.sky.z != 0.0f) {
-                    b.rad_r[path] += thr * cam.sky.x; b.rad_g[path] += thr * cam.sky.y; b.rad_b[path] += thr * cam.sky.z;
+            /* One read-modify-write of the path's radiance: first the visible light samples of
+             * the previous path vertex (entry i of this queue is slot i of that depth's samples),
+             * lights in order, then the sky if this ray left the scene (reference integrator.cpp:153). */
+            const bool sky_adds = !hit && (cam.sky.x != 0.0f || cam.sky.y != 0.0f || cam.sky.z != 0.0f);
+            const bool lights_add = depth > 0 && n_lights > 0;
+            if (sky_adds || lights_add) {
+                float r = b.rad_r[path], g = b.rad_g[path], bl = b.rad_b[path];
+                if (lights_add) {
+                    for (uint32_t l = 0; l < n_lights; l++) {
+                        const size_t j = (size_t)i * n_lights + l;
+                        if (b.sh_vis[nxt][j] == 1) { r += b.sh_wr[nxt][j]; g += b.sh_wg[nxt][j]; bl += b.sh_wb[nxt][j]; }
+                    }
                 }
+                if (sky_adds) {
+                    const float thr = b.thr[path];
+                    r += thr * cam.sky.x; g += thr * cam.sky.y; bl += thr * cam.sky.z;
+                }
+                b.rad_r[path] = r; b.rad_g[path] = g; b.rad_b[path] = bl;
             }
         }
         /* surviving paths keep one slot in the next queue and n_lights slots in the shadow queue */
@@ -663,9 +680,9 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
                     LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
                     const float wr = thr * ls.weight.x, wg = thr * ls.weight.y, wb = thr * ls.weight.z;
                     const size_t q = (size_t)slot0 * n_lights + j;
-                    b.sh_wr[q] = wr; b.sh_wg[q] = wg; b.sh_wb[q] = wb;
+                    b.sh_wr[cur][q] = wr; b.sh_wg[cur][q] = wg; b.sh_wb[cur][q] = wb;
                     trace[g] = trace_all || !(wr == 0.0f && wg == 0.0f && wb == 0.0f); /* NaN weights are traced */
-                    if (!trace[g]) b.sh_vis[q] = 0;
+                    if (!trace[g]) b.sh_vis[cur][q] = 0;
                     origin[g] = f.hit; dir[g] = ls.dir; dist[g] = ls.dist;
                 }
                 const uint64_t m = __ballot(trace[g]);
@@ -697,16 +714,17 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
     }
 }
 
-/* Adds the visible light samples of depth `depth` to their paths, lights in order. */
+/* Adds the visible light samples of depth `depth` to their paths, lights in order.  Used for
+ * the last depth only; the others are added by k_shade of the following depth. */
 __global__ __launch_bounds__(256) void k_accumulate(uint32_t n_lights, uint32_t depth, RenderBuffers b) {
     const uint32_t n = b.cnt[CNT_QUEUE + depth + 1];
-    const int nxt = (depth & 1) ^ 1;
+    const int cur = depth & 1, nxt = cur ^ 1;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t path = b.qpath[nxt][i];
         float r = b.rad_r[path], g = b.rad_g[path], bl = b.rad_b[path];
         for (uint32_t l = 0; l < n_lights; l++) {
             uint32_t j = i * n_lights + l;
-            if (b.sh_vis[j] == 1) { r += b.sh_wr[j]; g += b.sh_wg[j]; bl += b.sh_wb[j]; }
+            if (b.sh_vis[cur][j] == 1) { r += b.sh_wr[cur][j]; g += b.sh_wg[cur][j]; bl += b.sh_wb[cur][j]; }
         }
         b.rad_r[path] = r; b.rad_g[path] = g; b.rad_b[path] = bl;
     }
@@ -1261,9 +1279,11 @@ static int lane_ensure_scratch(RenderLane* f, size_t paths, uint32_t n_lights, s
     for (int c = 0; per_path[c] && !rc; c++) rc = film_alloc(f, per_path[c], P);
     if (!rc) rc = film_alloc(f, &b.pixel, P);
     if (!rc) rc = film_alloc(f, &b.sample, P);
-    float** per_sh[11] = {&b.sh.ox, &b.sh.oy, &b.sh.oz, &b.sh.dx, &b.sh.dy, &b.sh.dz, &b.sh_dist, &b.sh_wr, &b.sh_wg, &b.sh_wb, nullptr};
+    float** per_sh[14] = {&b.sh.ox, &b.sh.oy, &b.sh.oz, &b.sh.dx, &b.sh.dy, &b.sh.dz, &b.sh_dist, &b.sh_wr[0], &b.sh_wg[0], &b.sh_wb[0],
+                          &b.sh_wr[1], &b.sh_wg[1], &b.sh_wb[1], nullptr};
     for (int c = 0; per_sh[c] && !rc; c++) rc = film_alloc(f, per_sh[c], S);
-    if (!rc) rc = film_alloc(f, &b.sh_vis, S);
+    if (!rc) rc = film_alloc(f, &b.sh_vis[0], S);
+    if (!rc) rc = film_alloc(f, &b.sh_vis[1], S);
     if (!rc) rc = film_alloc(f, &b.sh_target, S);
     if (!rc) rc = film_alloc(f, &b.sh_defer, S);
     if (!rc) rc = film_alloc(f, &b.cnt, (size_t)CNT_WORDS);
@@ -1343,7 +1363,7 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
             sa.count_mul = 1;
             sa.target = b.sh_target;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
-            sa.dist = b.sh_dist; sa.vis = b.sh_vis;
+            sa.dist = b.sh_dist; sa.vis = b.sh_vis[cur];
             if (cam.shadow_mode == PT_SHADOW_BOUNDED) {
                 rc = launch_trace<TRACE_SHADOW_BOUNDED>(s, sa, &ctx);
                 if (rc) return rc;
@@ -1357,9 +1377,11 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
                 rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
                 if (rc) return rc;
             }
-            ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
-            hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, st, n_lights, depth, b);
-            HIP_TRY(hipGetLastError());
+            if (depth == 10) { /* the other depths' samples are added by the next depth's k_shade */
+                ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
+                hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, st, n_lights, depth, b);
+                HIP_TRY(hipGetLastError());
+            }
         }
     }
     if (after) HIP_TRY(hipStreamWaitEvent(st, after, 0));
@@ -1584,7 +1606,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     }
     /* Paths in flight: as many as allowed (a trace launch pays a fixed ramp-up and tail, the
      * latency of its longest rays, so longer queues run closer to the kernels' asymptotic rate:
-     * 32 -> 128 spp of 1080p per call is +13 %), but the scratch (96 bytes per path + 49 per
+     * 32 -> 128 spp of 1080p per call is +13 %), but the scratch (96 bytes per path + 62 per
      * shadow ray) stays within half of the GPU's memory and a batch's shadow rays within what one
      * trace launch accepts. */
     size_t limit = batch_paths_limit();
@@ -1592,7 +1614,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         const size_t L = (size_t)std::max(n_lights, 1);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        limit = std::min(limit, (total_b / 2) / (96 + 49 * L));
+        limit = std::min(limit, (total_b / 2) / (96 + 62 * L));
         limit = std::max<size_t>(limit, 4096);
     }
     /* With two lanes the call's paths go out as (at least) two batches that run on two streams
