@@ -180,6 +180,9 @@ def main():
             # rays are counted as the reference casts them; a shadow ray whose light sample has zero weight
             # cannot change the picture and is counted but not traced
             "shadow_rays_traced": int(traced_all),
+            "ray_counting": "value counts rays as the reference's rays_cast++ would (closest_rays + shadow_rays); "
+                            "shadow rays of light samples with exactly zero weight are in that count but are not traced "
+                            "(same picture bit for bit) -- traced_Mrays_per_s counts only rays that were traced",
             "traced_Mrays_per_s": round((closest_all + traced_all) / elapsed / 1e6, 2),
             "film_check": film_ok,
             "scene_prepare_s": round(t_prepare, 2),
