@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--level", type=int, default=8, help="icosphere subdivision level of the stand-in mesh (8 -> 1.31 M)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=128, help="one step = one batch of this many full-frame sample passes")
+    ap.add_argument("--spp-per-step", type=int, default=256, help="one step = one batch of this many full-frame sample passes")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -1194,6 +1194,7 @@ struct RenderLane {
     size_t cap_paths = 0;
     uint32_t cap_lights = 0;
     std::vector<void*> allocs;
+    size_t alloc_bytes = 0;
     RenderBuffers rb{};
     DLight* d_lights = nullptr;
     SubPass* d_sub = nullptr;
@@ -1219,7 +1220,7 @@ struct pt_film {
 
 static size_t batch_paths_limit() {
     const char* e = getenv("PT_BATCH_PATHS");
-    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 28;
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 29;
     if (v < 4096) v = 4096;
     if (v > ((size_t)1 << 30)) v = (size_t)1 << 30;
     return v;
@@ -1238,6 +1239,7 @@ static int render_lanes() {
 static void lane_free_scratch(RenderLane* f) {
     for (void* p : f->allocs) (void)hipFree(p);
     f->allocs.clear();
+    f->alloc_bytes = 0;
     f->cap_paths = 0; f->cap_lights = 0; f->cap_sub = 0;
     f->d_lights = nullptr; f->d_sub = nullptr; f->d_groups = nullptr;
 }
@@ -1254,6 +1256,7 @@ template <class T>
 static int film_alloc(RenderLane* f, T** out, size_t count) {
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    f->alloc_bytes += std::max<size_t>(count, 1) * sizeof(T);
     f->allocs.push_back(p);
     *out = (T*)p;
     return PT_OK;
@@ -1606,15 +1609,19 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
     }
     /* Paths in flight: as many as allowed (a trace launch pays a fixed ramp-up and tail, the
      * latency of its longest rays, so longer queues run closer to the kernels' asymptotic rate:
-     * 32 -> 128 spp of 1080p per call is +13 %), but the scratch (96 bytes per path + 62 per
-     * shadow ray) stays within half of the GPU's memory and a batch's shadow rays within what one
-     * trace launch accepts. */
+     * 32 -> 128 -> 256 spp of 1080p per call is +13 % and another +4 %), but the scratch (96 bytes
+     * per path + 62 per shadow ray; 152 GB for 2^29 paths and three lights) stays within nine tenths
+     * of the memory that is free on the GPU and a batch's shadow rays within what one trace launch
+     * accepts. */
     size_t limit = batch_paths_limit();
     {
         const size_t L = (size_t)std::max(n_lights, 1);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        limit = std::min(limit, (total_b / 2) / (96 + 62 * L));
+        /* what is free now plus what this film's lanes already hold, less a tenth */
+        size_t avail = free_b;
+        for (const RenderLane& ln : f->lane) avail += ln.alloc_bytes;
+        limit = std::min(limit, (avail / 10 * 9) / (96 + 62 * L));
         limit = std::max<size_t>(limit, 4096);
     }
     /* With two lanes the call's paths go out as (at least) two batches that run on two streams
