@@ -399,12 +399,13 @@ void RenderThread::kill_immediately() { send_message(RenderMessage({true, PassDe
 void* RenderThread::render_thread_main(void* cookie) {
     RenderThread* self = (RenderThread*)cookie;
     RenderEngine* eng = self->parent;
-    const size_t max_batch = 65536;
+    const size_t max_batch = 131072; /* tile passes per render call: 2^29 paths with 64x64 tiles */
     vector<pt_tile_pass> batch;
     vector<pt_light> lights;
     while (true) {
         sem_wait(&eng->messages_semaphore);
         bool die = false;
+        size_t taken = 0; /* messages in this batch (an entry of `batch` may stand for several) */
         batch.clear();
         pthread_mutex_lock(&eng->messages_lock);
         /* The message that woke us, then further ones already queued (each has a semaphore count
@@ -422,8 +423,16 @@ void* RenderThread::render_thread_main(void* cookie) {
                 break;
             }
             eng->messages.pop_front();
-            batch.push_back({m.desc.start_x, m.desc.start_y, m.desc.width, m.desc.height, m.sample, 1});
-            if (batch.size() >= take || sem_trywait(&eng->messages_semaphore) != 0) break;
+            taken++;
+            /* perform_full_passes queues all samples of a tile one after the other: a run of
+             * passes of one rectangle with consecutive sample numbers is ONE entry of the call */
+            if (!batch.empty() && batch.back().x == m.desc.start_x && batch.back().y == m.desc.start_y &&
+                batch.back().w == m.desc.width && batch.back().h == m.desc.height &&
+                batch.back().first_sample + batch.back().n_samples == m.sample)
+                batch.back().n_samples++;
+            else
+                batch.push_back({m.desc.start_x, m.desc.start_y, m.desc.width, m.desc.height, m.sample, 1});
+            if (taken >= take || sem_trywait(&eng->messages_semaphore) != 0) break;
         }
         pthread_mutex_unlock(&eng->messages_lock);
         if (die) break;
@@ -445,14 +454,14 @@ void* RenderThread::render_thread_main(void* cookie) {
             else cerr << "render worker: " << pt_last_error() << endl;
         }
         in->last_pass_seconds = now_seconds() - t0;
-        in->passes += (int)batch.size();
+        in->passes += (int)taken;
         pthread_mutex_unlock(&self->integrator_lock);
         self->is_running = false;
 
         pthread_mutex_lock(&eng->master_lock);
-        eng->total_passes_completed += (int)batch.size();
+        eng->total_passes_completed += (int)taken;
         pthread_mutex_unlock(&eng->master_lock);
-        for (size_t i = 0; i < batch.size(); i++) sem_post(&eng->passes_semaphore);
+        for (size_t i = 0; i < taken; i++) sem_post(&eng->passes_semaphore);
     }
     return nullptr;
 }
