@@ -39,7 +39,8 @@ extern "C" {
 #define PT_MAX_TRIANGLES   ((1u << 26) - 64u)
 #define PT_MAX_TREE_DEPTH  20      /* interior levels above any leaf; reference caps at 19 (kdtree.cpp:13) */
 #define PT_MAX_LIGHTS      16
-#define PT_MAX_RAYS_PER_CALL 0xf0000000ull  /* rays of one ray-cast call (ray indices are 32-bit) */
+#define PT_MAX_RAYS_PER_CALL 0x7fffffffull  /* rays of one ray-cast call: a lane holds its ray's index as a signed
+                                               32-bit word whose sign means "idle" */
 
 /* One interior node of the reference's tree (kdTreeNode, kdtree.h:19-36), holding the
  * AABBs of BOTH children so a visit needs one 64-byte load.  The node's own box lives in

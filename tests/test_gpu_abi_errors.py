@@ -63,6 +63,12 @@ def test_null_and_limit_arguments(scene_small):
     assert L.pt_raycast_closest(gpu.h, 4, None, None, None, None, None, None, None, None, None, None) == -1
     assert L.pt_raycast_closest(None, 4, None, None, None, None, None, None, None, None, None, None) == -1
     assert L.pt_raycast_closest(gpu.h, 0, None, None, None, None, None, None, None, None, None, None) == 0
+    # one call takes at most PT_MAX_RAYS_PER_CALL = 2^31 - 1 rays (a lane keeps its ray's index in a
+    # signed word); a longer request is refused before any pointer is touched
+    fake = [C.c_void_p(0x1000)] * 10
+    assert L.pt_raycast_closest_dev(gpu.h, 1 << 31, *fake) == -4
+    assert L.pt_raycast_shadow_dev(gpu.h, 1 << 31, *fake[:8]) == -4
+    assert L.pt_raycast_occluded_dev(gpu.h, (1 << 32) + 5, *fake[:8]) == -4
     film = pta.Film(gpu, 32, 16)
     cam = pta.cli_camera()
     with pytest.raises(PtError):
