@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <map>
@@ -162,6 +163,20 @@ inline V3 project_to_altitude(const Tri& tr, V3 point, float altitude) {
     return point + change * tr.normal;
 }
 
+/* Runs f(a, b) over [0, n) cut into at most `threads` consecutive ranges, one thread each. */
+template <typename F>
+void parallel_for(int64_t n, int threads, F f) {
+    if (threads <= 1 || n < 2) { f(0, n); return; }
+    std::vector<std::thread> pool;
+    int64_t chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        int64_t a = t * chunk, b = std::min(n, a + chunk);
+        if (a >= b) break;
+        pool.emplace_back([=]() { f(a, b); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 /* --------------------------------------------------- STL + vertex normals */
 
 struct V3Less { /* stlreader.cpp:46-60 */
@@ -175,8 +190,77 @@ struct V3Less { /* stlreader.cpp:46-60 */
 };
 
 /* stlreader.cpp:62-81: vertex normal = normalised sum (in mesh order) of the face normals
- * of every triangle corner that is bit-identical to the vertex. */
-void compute_barycentric_normals(std::vector<Tri>& tris) {
+ * of every triangle corner that is bit-identical to the vertex.
+ *
+ * The reference keys a std::map<Vec, vector<int>> by the corner points and appends triangle
+ * indices in mesh order.  Here the corners are SORTED by (point under the same ordering, corner
+ * number) instead: a run of corners that the ordering cannot tell apart is one map entry, and
+ * inside a run the corner numbers ascend, which is the map's append order -- so every sum adds
+ * the same normals in the same order.  The order is total, hence the sorted sequence does not
+ * depend on how it is produced, and it is produced by a threaded merge sort (64 M corners of the
+ * largest test scene take minutes through a map). */
+void compute_barycentric_normals(std::vector<Tri>& tris, int threads) {
+    const int64_t nc = (int64_t)tris.size() * 3;
+    if (threads < 1) threads = 1;
+    V3Less less;
+    auto before = [&](int64_t a, int64_t b) {
+        const V3& pa = tris[(size_t)(a / 3)].p[a % 3];
+        const V3& pb = tris[(size_t)(b / 3)].p[b % 3];
+        if (less(pa, pb)) return true;
+        if (less(pb, pa)) return false;
+        return a < b;
+    };
+    std::vector<int64_t> order((size_t)nc), tmp;
+    for (int64_t c = 0; c < nc; c++) order[(size_t)c] = c;
+    int parts = 1;
+    while (parts < threads && nc / (parts * 2) >= 65536) parts *= 2;
+    const int64_t chunk = (nc + parts - 1) / parts;
+    parallel_for(parts, parts, [&](int64_t a, int64_t b) {
+        for (int64_t k = a; k < b; k++)
+            std::sort(order.begin() + std::min(nc, k * chunk), order.begin() + std::min(nc, (k + 1) * chunk), before);
+    });
+    for (int64_t width = chunk; width < nc; width *= 2) {     /* merge neighbouring sorted runs */
+        tmp.resize((size_t)nc);
+        const int64_t pairs = (nc + 2 * width - 1) / (2 * width);
+        parallel_for(pairs, threads, [&](int64_t a, int64_t b) {
+            for (int64_t k = a; k < b; k++) {
+                const int64_t lo = k * 2 * width, mid = std::min(nc, lo + width), hi = std::min(nc, lo + 2 * width);
+                std::merge(order.begin() + lo, order.begin() + mid, order.begin() + mid, order.begin() + hi, tmp.begin() + lo, before);
+            }
+        });
+        order.swap(tmp);
+    }
+    /* runs of equal points; every corner of a run gets the run's sum */
+    std::vector<V3> corner_normal((size_t)nc);
+    std::vector<int64_t> run_start;
+    for (int64_t i = 0; i < nc; i++) {
+        if (i == 0) { run_start.push_back(0); continue; }
+        const int64_t a = order[(size_t)i - 1], b = order[(size_t)i];
+        const V3& pa = tris[(size_t)(a / 3)].p[a % 3];
+        const V3& pb = tris[(size_t)(b / 3)].p[b % 3];
+        if (less(pa, pb) || less(pb, pa)) run_start.push_back(i);
+    }
+    run_start.push_back(nc);
+    parallel_for((int64_t)run_start.size() - 1, threads, [&](int64_t a, int64_t b) {
+        for (int64_t r = a; r < b; r++) {
+            V3 n = mk(0, 0, 0);
+            for (int64_t i = run_start[(size_t)r]; i < run_start[(size_t)r + 1]; i++) n = n + tris[(size_t)(order[(size_t)i] / 3)].normal;
+            const V3 vn = normalized(n);
+            for (int64_t i = run_start[(size_t)r]; i < run_start[(size_t)r + 1]; i++) corner_normal[(size_t)order[(size_t)i]] = vn;
+        }
+    });
+    for (size_t i = 0; i < tris.size(); i++) {
+        Tri& tr = tris[i];
+        const V3* vn = &corner_normal[i * 3];
+        tr.base_n = vn[0];          /* utils.cpp:131-135 */
+        tr.u_n = vn[1] - vn[0];
+        tr.v_n = vn[2] - vn[0];
+    }
+}
+
+/* The reference's formulation word for word (a std::map keyed by the points); kept so that the
+ * tests can hold the sorted formulation above against it. */
+void compute_barycentric_normals_map(std::vector<Tri>& tris) {
     std::map<V3, std::vector<int>, V3Less> point_to_tris;
     for (size_t i = 0; i < tris.size(); i++)
         for (int k = 0; k < 3; k++) point_to_tris[tris[i].p[k]].push_back((int)i);
@@ -187,7 +271,7 @@ void compute_barycentric_normals(std::vector<Tri>& tris) {
             for (int other : point_to_tris[tr.p[k]]) n = n + tris[other].normal;
             vn[k] = normalized(n);
         }
-        tr.base_n = vn[0];          /* utils.cpp:131-135 */
+        tr.base_n = vn[0];
         tr.u_n = vn[1] - vn[0];
         tr.v_n = vn[2] - vn[0];
     }
@@ -231,6 +315,7 @@ struct Node {
 struct BuildCtx {
     const std::vector<Tri>* mesh;
     int spawn_depth; /* children above this depth are built on their own thread */
+    int threads;     /* threads of the whole build; a node at depth d may use threads >> d of them */
 };
 
 typedef std::vector<int> IdxList;
@@ -255,8 +340,22 @@ Node* build_node(const BuildCtx& ctx, int depth, IdxList lists[2][3]) {
     if (count < 10000) inc = 4;
     if (count < 1000) inc = 2;
     if (count < 100) inc = 1;
-    for (int axis = 0; axis < 3; axis++) {
-        for (unsigned int tt = 0; tt < count; tt += inc) {
+    /* The candidates in the reference's order (axis 0 first, then along the by-minimum-x list),
+     * the winner being the FIRST one with the smallest score (strict '<', kdtree.cpp:129-143).
+     * Wide nodes cut that sequence into consecutive ranges scored on several threads; taking the
+     * ranges' winners in order with the same strict '<' picks the same candidate. */
+    struct Best { float split; int axis; float score; };
+    const unsigned int per_axis = (count + inc - 1) / inc;
+    const int node_threads = count >= 200000 ? std::max(1, ctx.threads >> std::min(depth, 30)) : 1;
+    std::vector<Best> part((size_t)node_threads, Best{0.0f, -1, F_INF});
+    std::vector<int> part_used((size_t)node_threads, 0);
+    const int64_t total_cand = (int64_t)per_axis * 3;
+    const int64_t cand_chunk = (total_cand + node_threads - 1) / node_threads;
+    parallel_for(total_cand, node_threads, [&](int64_t a, int64_t b) {
+        Best best{0.0f, -1, F_INF};
+        for (int64_t c = a; c < b; c++) {
+            const int axis = (int)(c / per_axis);
+            const unsigned int tt = (unsigned int)(c % per_axis) * (unsigned int)inc;
             float sample = mesh[ours[tt]].box.hi(axis);
             int side[2] = {0, 0};
             for (int mm = 0; mm < 2; mm++) {
@@ -271,20 +370,30 @@ Node* build_node(const BuildCtx& ctx, int depth, IdxList lists[2][3]) {
                 else side[mm] = (int)(count - high);
             }
             float score = real_max((float)side[0], (float)side[1]);
-            if (score < best_score) { best_split = sample; best_axis = axis; best_score = score; }
+            if (score < best.score) { best.split = sample; best.axis = axis; best.score = score; }
         }
-    }
+        part[(size_t)(a / cand_chunk)] = best;
+        part_used[(size_t)(a / cand_chunk)] = 1;
+    });
+    for (int k = 0; k < node_threads; k++)
+        if (part_used[(size_t)k] && part[(size_t)k].score < best_score) {
+            best_split = part[(size_t)k].split; best_axis = part[(size_t)k].axis; best_score = part[(size_t)k].score;
+        }
     n->axis = best_axis;
     n->split = best_split;
     IdxList lo_l[2][3], hi_l[2][3];
-    for (int axis = 0; axis < 3; axis++)
-        for (int mm = 0; mm < 2; mm++)
+    /* the six lists are filtered independently of one another (one thread each on wide nodes) */
+    parallel_for(6, node_threads > 1 ? 6 : 1, [&](int64_t a, int64_t b) {
+        for (int64_t k = a; k < b; k++) {
+            const int axis = (int)(k / 2), mm = (int)(k % 2);
             for (unsigned int i = 0; i < count; i++) {
                 int ti = lists[mm][axis][i];
                 bool below = mesh[ti].box.lo(best_axis) <= best_split; /* kdtree.cpp:172-183 */
                 if (below) lo_l[mm][axis].push_back(ti);
                 else hi_l[mm][axis].push_back(ti);
             }
+        }
+    });
     unsigned int lo_n = (unsigned int)lo_l[0][0].size(), hi_n = (unsigned int)hi_l[0][0].size();
     if (hi_n == count || lo_n == count) { /* kdtree.cpp:206-208: no improvement -> leaf */
         n->leaf = true;
@@ -310,19 +419,22 @@ Node* build_node(const BuildCtx& ctx, int depth, IdxList lists[2][3]) {
  * this input sequence; using std::sort on the same sequence reproduces it. */
 Node* build_tree(const std::vector<Tri>& mesh, int threads) {
     IdxList lists[2][3];
-    for (int axis = 0; axis < 3; axis++) {
-        for (int mm = 0; mm < 2; mm++) {
+    /* six independent sorts of the same initial sequence: one thread each gives the same lists */
+    parallel_for(6, threads > 1 ? 6 : 1, [&](int64_t a, int64_t b) {
+        for (int64_t k = a; k < b; k++) {
+            const int axis = (int)(k / 2), mm = (int)(k % 2);
             IdxList& l = lists[mm][axis];
             l.resize(mesh.size());
             for (size_t i = 0; i < mesh.size(); i++) l[i] = (int)i;
+            if (mm == 0)
+                std::sort(l.begin(), l.end(), [&](const int& x, const int& y) { return mesh[x].box.lo(axis) < mesh[y].box.lo(axis); });
+            else
+                std::sort(l.begin(), l.end(), [&](const int& x, const int& y) { return mesh[x].box.hi(axis) < mesh[y].box.hi(axis); });
         }
-        std::sort(lists[0][axis].begin(), lists[0][axis].end(),
-                  [&](const int& a, const int& b) { return mesh[a].box.lo(axis) < mesh[b].box.lo(axis); });
-        std::sort(lists[1][axis].begin(), lists[1][axis].end(),
-                  [&](const int& a, const int& b) { return mesh[a].box.hi(axis) < mesh[b].box.hi(axis); });
-    }
+    });
     BuildCtx ctx;
     ctx.mesh = &mesh;
+    ctx.threads = threads;
     ctx.spawn_depth = 0;
     while ((1 << ctx.spawn_depth) < threads) ctx.spawn_depth++;
     return build_node(ctx, 0, lists);
@@ -629,19 +741,6 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
     return energy;
 }
 
-template <typename F>
-void parallel_for(int64_t n, int threads, F f) {
-    if (threads <= 1 || n < 2) { f(0, n); return; }
-    std::vector<std::thread> pool;
-    int64_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        int64_t a = t * chunk, b = std::min(n, a + chunk);
-        if (a >= b) break;
-        pool.emplace_back([=]() { f(a, b); });
-    }
-    for (auto& th : pool) th.join();
-}
-
 inline Ray input_ray(const float* o, const float* d, int64_t i, int normalize) {
     V3 oo = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
     V3 dd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
@@ -650,7 +749,9 @@ inline Ray input_ray(const float* o, const float* d, int64_t i, int normalize) {
 }
 
 void finish_scene(Scene* s, int threads) {
-    compute_barycentric_normals(s->mesh);
+    const char* how = getenv("ORC_VERTEX_NORMALS");      /* "map": the reference's std::map formulation */
+    if (how && strcmp(how, "map") == 0) compute_barycentric_normals_map(s->mesh);
+    else compute_barycentric_normals(s->mesh, threads);
     s->root = build_tree(s->mesh, threads < 1 ? 1 : threads);
 }
 

@@ -99,6 +99,33 @@ def rays_hostile(tris, n, seed=8):
     return o.astype(np.float32), d.astype(np.float32)
 
 
+def oversized_leaf_mesh(k=24, per_leaf=40):
+    """k*k groups of `per_leaf` triangles that all have the SAME bounding box (they share the box
+    diagonal, the third vertex slides across it), so no split separates a group: the builder
+    makes each group one leaf (reference kdtree.cpp:206-208) of more than 15 triangles, the size
+    at which a child reference no longer holds the leaf's triangle count."""
+    s = np.linspace(0.05, 0.95, per_leaf, dtype=np.float32)
+    t = np.zeros((per_leaf, 9), np.float32)
+    t[:, 3:6] = 1.0
+    t[:, 6] = s
+    t[:, 7] = 1 - s
+    t[:, 8] = 0.5
+    shifts = np.stack(np.meshgrid(np.arange(k), np.arange(k), indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float32) * 1.5
+    return np.concatenate([t + np.tile(np.array([sx, sy, 0], np.float32), 3) for sx, sy in shifts], axis=0)
+
+
+def rays_over_grid(n, extent, seed=4):
+    """Rays from above and below a slab [0, extent]^2 x [0, 1], tilted a little."""
+    rng = np.random.default_rng(seed)
+    o = np.empty((n, 3), np.float32)
+    o[:, :2] = rng.random((n, 2)).astype(np.float32) * extent
+    o[:, 2] = np.where(rng.random(n) < 0.5, 5.0, -5.0)
+    d = rng.normal(size=(n, 3)).astype(np.float32) * np.float32(0.15)
+    d[:, 2] = -np.sign(o[:, 2])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
 def all_ray_sets(tris, n=20000):
     cam = orc.cli_camera()
     sets = {

@@ -55,16 +55,20 @@ def test_lane_shadow(scene_small, scene_medium):
             assert np.array_equal(vis, sc.oracle.shadow_visible(o, d, dist)), name
 
 
-def test_oversized_leaf(scene_small):
+def test_oversized_leaf():
     """Leaves with more than 15 triangles keep their count in the first triangle record."""
-    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)
-    t = np.repeat(one, 40, axis=0)
-    t[:, 2::3] += np.linspace(0, 0.5, 40, dtype=np.float32)[:, None]   # stack them along z, same x/y boxes
+    from conftest import oversized_leaf_mesh, rays_over_grid
+    t = oversized_leaf_mesh(6)
     host = pta.HostScene(t)
     oracle = orc.Scene(t)
+    assert host.tree_stats() == oracle.tree_stats() and host.tree_stats()["largest_leaf"] == 40
+    nodes, tris, _ = host.flat_arrays()
+    refs = np.concatenate([nodes["lo_ref"], nodes["hi_ref"]])
+    leaf_refs = refs[(refs & 0x80000000) != 0]
+    assert len(leaf_refs) == 36 and ((leaf_refs >> 26) & 0xF == 0).all()    # count field 0: read it from the record
+    assert (tris["leaf_count"][leaf_refs & 0x03FFFFFF] == 40).all()
     E = load_emul()
-    o = np.array([[0.2, 0.2, 5.0], [0.2, 0.2, -5.0], [0.9, 0.9, 5.0]], np.float32)
-    d = np.array([[0, 0, -1], [0, 0, 1], [0, 0, -1]], np.float32)
+    o, d = rays_over_grid(5000, 6 * 1.5)
     got, _, _ = emul_closest(E, host, o, d)
     assert_hits_equal(got, oracle.raycast(o, d))
-    assert got[0][0] >= 0 and got[0][2] == -1
+    assert 0.2 < (got[0] >= 0).mean() < 1.0

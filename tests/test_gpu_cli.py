@@ -79,6 +79,18 @@ def test_animate_frames_match_single_renders(tmp_path, scene_small):
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout + res.stderr
         assert np.array_equal(frames[f], _read_png(single)), f
+    # and against the CPU oracle: the last frame's camera (angle 1.6) and plane of focus (4.5) are
+    # those the driver set for THAT frame -- the workers re-read them per batch while the geometry
+    # stays on the GPU -- and every frame restarts at sample 0
+    f = F - 1
+    cam = orc.cli_camera(angle=1.0 + 0.3 * f, dof_aperture=0.1, dof_distance=4.0 + 0.25 * f)
+    rgb, passes, _ = scene_small.oracle.render(cam, orc.cli_lights(), W, H, None, 0, S, seed=7)
+    assert (passes == S).all()
+    want = orc.tonemap(rgb, passes).reshape(H, W, 3)
+    diff = np.abs(frames[f].astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+    # a frame of another camera is a different picture altogether
+    assert np.abs(frames[0].astype(int) - want.astype(int)).max() > 16
 
 
 def test_checkpoint_and_resume(tmp_path, scene_small):

@@ -114,3 +114,22 @@ def test_degenerate_inputs():
         o = orc.Scene(t)
         assert h.tree_stats() == o.tree_stats()
         assert h.tree_stats()["leaves"] == 1 and h.tree_stats()["largest_leaf"] == reps
+
+
+def test_tree_identity_at_full_size():
+    """1.34 M triangles: the sizes at which the builder samples every 8th split candidate
+    (reference kdtree.cpp:92-98) and hands the widest nodes to all threads at once.  Host tree ==
+    oracle tree bit for bit, from one thread and from many."""
+    tris = pta.meshgen.standin_scene(8)
+    oracle = orc.Scene(tris, threads=8)
+    want_nodes, want_leaves = oracle.tree_dump()
+    want_stats = oracle.tree_stats()
+    assert want_stats["max_depth"] == 19 and want_stats["leaf_triangles"] == len(tris)
+    del oracle
+    for threads in (1, 16):
+        host = pta.HostScene(tris, threads=threads)
+        assert host.tree_stats() == want_stats
+        nodes, leaves = host.tree_dump()
+        assert np.array_equal(bits(nodes), bits(want_nodes)), threads
+        assert np.array_equal(leaves, want_leaves), threads
+        host.close()

@@ -194,3 +194,20 @@ def test_bounded_shadow_mode(scene_small):
     assert np.array_equal(out[0][1], out[1][1])
     assert out[1][0].min() > 1.0          # every pixel sees the lit floor
     assert out[0][0].sum() < 0.05 * out[1][0].sum()
+
+
+def test_vertex_normals_sorted_formulation_equals_the_map(scene_medium, monkeypatch):
+    """The oracle welds corners by sorting them; the reference's own formulation (a std::map keyed
+    by the points, stlreader.cpp:62-81) is kept beside it and must give the same bits -- also for
+    vertices that differ only in the sign of a zero, which the map's ordering cannot tell apart."""
+    tris = scene_medium.tris.copy()
+    tris[::7, 2] = 0.0
+    tris[::7, 5] = -0.0
+    tris[::14, 8] = 0.0
+    tris[1::14, 8] = -0.0
+    fast = orc.Scene(tris, threads=5).triangle_data()
+    monkeypatch.setenv("ORC_VERTEX_NORMALS", "map")
+    slow = orc.Scene(tris, threads=5).triangle_data()
+    assert np.array_equal(bits(fast), bits(slow))
+    monkeypatch.delenv("ORC_VERTEX_NORMALS")
+    assert np.array_equal(bits(orc.Scene(tris, threads=1).triangle_data()), bits(fast))
