@@ -139,6 +139,21 @@ int pt_raycast_occluded_dev(pt_scene* s, uint64_t n,
                             const float* d_dx, const float* d_dy, const float* d_dz,
                             const float* d_max_t, uint8_t* d_visible);
 
+/* pt_raycast_closest_dev for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same
+ * arguments, same results bit for bit, asynchronous on the scene's stream; it calls no
+ * hipMalloc/hipFree and no allocating library routine.  The scratch the trace kernel needs (ray
+ * count, queue heads, stack spill area) lives in a static device array of 44 MiB + 1 KiB that each
+ * GPU the library runs on holds until the process ends, which bounds the launch to 1024 workgroups
+ * and the call to PT_NOALLOC_MAX_RAYS rays (more: PT_ERR_LIMIT).  All calls on one GPU -- from any
+ * scene handle -- share that GPU's array: calls that overlap in time on one GPU race; keep them
+ * on one stream or wait (pt_scene_sync) between them. */
+#define PT_NOALLOC_MAX_RAYS (1ull << 24)
+int pt_raycast_closest_dev_noalloc(pt_scene* s, uint64_t n,
+                                   const float* d_ox, const float* d_oy, const float* d_oz,
+                                   const float* d_dx, const float* d_dy, const float* d_dz,
+                                   int32_t* d_tri_index, float* d_t, float* d_u, float* d_v);
+
 int pt_scene_sync(pt_scene* s);
 
 /* Milliseconds the GPU spent in this scene's kernels of one class since the last call with

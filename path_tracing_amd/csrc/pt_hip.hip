@@ -804,6 +804,27 @@ __global__ void k_film_add(float4* film, size_t n, const float* rgb, const int32
     film[i] = v;
 }
 
+/* ------------------------------------------------- scratch that is never allocated */
+
+/* Scratch of pt_raycast_closest_dev_noalloc: what the other entry points keep in hipMalloc'ed
+ * buffers of the scene (ray count and queue heads; the stack spill area of the trace grid), in a
+ * file-scope device array instead, so that the call allocates nothing.  Every GPU the library
+ * runs on holds its own copy of the array (at its own address) until the process ends:
+ * NOALLOC_WORDS * 4 bytes = 44 MiB + 1 KiB.  The array's name is only a host-side handle; the
+ * address kernels and memsets use is looked up once per device with hipGetSymbolAddress
+ * (pt_scene_create) and kept in the scene. */
+#define NOALLOC_GRID 1024u                                    /* workgroups of the no-alloc trace launch (4 per CU) */
+#define NOALLOC_HEAD_WORDS 256u                               /* [0] ray count, queue heads from SMALL_HEADS0 on */
+#define NOALLOC_SPILL_WORDS (NOALLOC_GRID * TRACE_BLOCK * (STACK_MAX_CLOSEST - STACK_LDS))
+#define NOALLOC_WORDS (NOALLOC_HEAD_WORDS + NOALLOC_SPILL_WORDS)
+static __device__ __align__(256) uint32_t scratch[NOALLOC_WORDS];
+
+/* Ray count into word 0, zero into the queue heads: the spill area needs no clearing (a lane
+ * only reads stack entries it has written during the same ray). */
+__global__ __launch_bounds__(NOALLOC_HEAD_WORDS) void k_noalloc_prepare(uint32_t* head, uint32_t n) {
+    head[threadIdx.x] = threadIdx.x == 0 ? n : 0u;
+}
+
 /* --------------------------------------------------------------- host side */
 
 struct TimedLaunch { int cls; hipEvent_t a, b; };
@@ -828,6 +849,7 @@ struct pt_scene {
     uint64_t n_tris = 0;
     uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, two sets of queue heads at SMALL_HEADS0/1 */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
+    uint32_t* d_static_scratch = nullptr; /* this device's copy of `scratch` (never allocated, never freed) */
     /* second render lane (see pt_render_passes): its own stream and spill area, made on first use */
     hipStream_t stream2 = nullptr;
     uint32_t* d_spill2 = nullptr;
@@ -975,6 +997,12 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     s->d.root_ref = flat->root_ref;
     s->d.n_tris = (uint32_t)flat->n_tris;
     if (init_trace_launch(s) != PT_OK) return cleanup(PT_ERR_DEVICE);
+    {   /* the address of this device's copy of the static scratch array (the device is current) */
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return cleanup(fail(PT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e)));
+        s->d_static_scratch = (uint32_t*)p;
+    }
     s->d.root.mnx = flat->root_min[0]; s->d.root.mny = flat->root_min[1]; s->d.root.mnz = flat->root_min[2];
     s->d.root.mxx = flat->root_max[0]; s->d.root.mxy = flat->root_max[1]; s->d.root.mxz = flat->root_max[2];
     *out = s;
@@ -1140,6 +1168,30 @@ int pt_raycast_occluded_dev(pt_scene* s, uint64_t n, const float* ox, const floa
     a.d_count = s->d_small; a.d_next_chunk = s->d_small + SMALL_HEADS0;
     a.dist = max_t; a.vis = vis;
     return launch_trace<TRACE_SHADOW_BOUNDED>(s, a);
+}
+
+int pt_raycast_closest_dev_noalloc(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                                   const float* dy, const float* dz, int32_t* idx, float* t, float* u, float* v) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !idx || !t || !u || !v) return fail(PT_ERR_INVALID, "null array");
+    if (n > PT_NOALLOC_MAX_RAYS) return fail(PT_ERR_LIMIT, "more than PT_NOALLOC_MAX_RAYS rays in one no-alloc call");
+    int rc = set_device(s);
+    if (rc) return rc;
+    if (s->n_tris == 0) return fill_miss_closest(s, n, idx, t, u, v);
+    uint32_t* head = s->d_static_scratch;   /* the looked-up device address, never the array's name */
+    hipLaunchKernelGGL(k_noalloc_prepare, dim3(1), dim3(NOALLOC_HEAD_WORDS), 0, s->stream, head, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+    TraceArgs a{};
+    a.rays = {ox, oy, oz, dx, dy, dz};
+    a.d_count = head; a.count_mul = 1; a.d_next_chunk = head + SMALL_HEADS0;
+    a.out_idx = idx; a.out_t = t; a.out_u = u; a.out_v = v;
+    a.spill = head + NOALLOC_HEAD_WORDS;
+    /* no launch timing here: the timers take events from a pool that may have to grow */
+    const unsigned grid = std::min<unsigned>((unsigned)s->grid_closest, NOALLOC_GRID);
+    hipLaunchKernelGGL(k_trace<TRACE_CLOSEST_MESH>, dim3(grid), dim3(TRACE_BLOCK), 0, s->stream, s->d, a);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
 }
 
 } // extern "C"

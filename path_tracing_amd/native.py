@@ -95,6 +95,7 @@ def host_lib():
 
 HIP_SYMBOLS = [
     "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_raycast_closest", "pt_raycast_closest_dev",
+    "pt_raycast_closest_dev_noalloc",
     "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_raycast_occluded", "pt_raycast_occluded_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_film_create",
     "pt_film_destroy", "pt_film_zero", "pt_film_device_ptr", "pt_film_read", "pt_film_add", "pt_films_reduce", "pt_render_passes",
     "pt_camera_rays_dev", "pt_last_error", "pt_build_info",
@@ -124,6 +125,7 @@ def hip_lib():
         L.pt_scene_destroy.restype = None
         L.pt_raycast_closest.argtypes = [vp, u64] + [vp] * 10
         L.pt_raycast_closest_dev.argtypes = [vp, u64] + [vp] * 10
+        L.pt_raycast_closest_dev_noalloc.argtypes = [vp, u64] + [vp] * 10
         L.pt_raycast_shadow.argtypes = [vp, u64] + [vp] * 8
         L.pt_raycast_shadow_dev.argtypes = [vp, u64] + [vp] * 8
         L.pt_raycast_occluded.argtypes = [vp, u64] + [vp] * 8

@@ -200,11 +200,13 @@ class GpuScene:
         return vis
 
     # -- device-pointer entry points (torch tensors on this device) ----------------------
-    def raycast_closest_dev(self, rays, out_idx, out_t, out_u, out_v):
-        """rays: six float32 CUDA tensors (ox, oy, oz, dx, dy, dz) of equal length."""
+    def raycast_closest_dev(self, rays, out_idx, out_t, out_u, out_v, noalloc=False):
+        """rays: six float32 CUDA tensors (ox, oy, oz, dx, dy, dz) of equal length.
+        noalloc selects the entry point whose scratch is a static device array."""
         n = rays[0].numel()
         ptrs = [C.c_void_p(r.data_ptr()) for r in rays]
-        check(native.hip_lib().pt_raycast_closest_dev(
+        fn = native.hip_lib().pt_raycast_closest_dev_noalloc if noalloc else native.hip_lib().pt_raycast_closest_dev
+        check(fn(
             self.h, n, *ptrs, C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_t.data_ptr()),
             C.c_void_p(out_u.data_ptr()), C.c_void_p(out_v.data_ptr())), "pt_raycast_closest_dev")
 
