@@ -7,16 +7,23 @@
 Workload (BASELINE.json configs[2], the configuration the metric "Mrays/s (all bounces)" is
 quoted on): full path trace of the ~1.3 M-triangle stand-in object on its floor, 3 lights,
 mirror bounces (the reference's HEAD behaviour), Gaussian-aperture depth of field,
-1920x1080.  One step = one batch of --spp-per-step full-frame sample passes.  With N GPUs
-every rank renders its own sample range into its own film (weak scaling: per-GPU work is
-fixed) and the films are summed to rank 0 by one RCCL reduce inside the timed region.
+1920x1080.
 
-Prints ONE JSON line on rank 0.  `value` counts what the reference's `rays_cast++`
-(kdtree.cpp:578) would count -- closest-hit plus shadow casts -- per second of wall time,
-with scene and film resident in HBM before the clock starts.
+Default (weak scaling): one step = one batch of --spp-per-step full-frame sample passes per GPU;
+every rank renders its own sample range into its own film and the films are summed to rank 0 by
+one RCCL reduce inside the timed region.  After the timed steps the same processes render ONE
+frame of --strong-spp samples (default 1000) split over the ranks by sample index
+(path_tracing_amd.distributed.partition_samples), reduce included, and report its wall time as
+`strong_scaling` -- the "1080p @ 1000 spp on N GPUs" figure.  With --total-spp T that frame IS the
+step (strong scaling: the work per step is fixed, each rank renders T/N samples).
+
+Prints ONE JSON line on rank 0.  `value` counts the rays that were traced -- closest-hit casts
+plus the shadow rays of light samples with a non-zero weight -- per second of wall time, with
+scene and film resident in HBM before the clock starts; `reference_counted_Mrays_per_s` counts
+what the reference's `rays_cast++` (kdtree.cpp:578) would, i.e. also the shadow rays of
+zero-weight light samples, which are counted but not traced.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -27,8 +34,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-CU_GATHER_PEAK_GBS = 13400.0  # measured: scattered 64-byte records through the CUs' vector-memory path, L2-resident
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+# Ceiling for a working set that lives in L2 / Infinity Cache: what the compute units' vector-memory
+# path delivers for gathers of L2-resident rows, chip-wide (hardware guide: 16.8-18.8 TB/s measured;
+# the L2's aggregate bandwidth is 34.5 TB/s).  This repository's own micro-benchmark of the exact
+# access shape (64 lanes each loading their own 64-byte record) gets 13.4 TB/s.
+L2_GATHER_PEAK_GBS = 16800.0
+OWN_GATHER_RATE_GBS = 13400.0
+INFINITY_CACHE_BYTES = 256 << 20
 
 
 def parse():
@@ -39,10 +52,15 @@ def parse():
     ap.add_argument("--level", type=int, default=8, help="icosphere subdivision level of the stand-in mesh (8 -> 1.31 M)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=256, help="one step = one batch of this many full-frame sample passes")
+    ap.add_argument("--spp-per-step", type=int, default=256, help="weak mode: one step = this many full-frame sample passes per GPU; "
+                                                                   "also the largest batch handed to one render call")
+    ap.add_argument("--total-spp", type=int, default=0, help="strong mode: one step = one frame of this many samples split over the ranks")
+    ap.add_argument("--strong-spp", type=int, default=1000, help="weak mode: samples of the extra strong-scaling frame (0: skip it)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="run the N-rank code path on ONE GPU: gloo backend, every rank on device 0, films reduced through host copies")
     return ap.parse_args()
 
 
@@ -57,16 +75,16 @@ def host_threads(world):
     return max(1, min(16, avail // max(world, 1)) or 1)
 
 
-def measured_traffic(rays_per_launch):
-    """HBM-side bytes per launch of the closest-hit kernel, from the rocprofv3 PMC pass recorded in
-    profiles/traffic.json (FETCH_SIZE + WRITE_SIZE per ray of the same bench command, FETCH_SIZE
-    doubled as the gfx950 correction requires), scaled to this run's rays per launch."""
+def measured_traffic(key):
+    """HBM-side bytes per ray of the trace kernels for workload `key`, from the rocprofv3 PMC passes
+    recorded in profiles/traffic.json (FETCH_SIZE + WRITE_SIZE per ray of the same bench command,
+    FETCH_SIZE doubled as the gfx950 correction requires)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fp:
             t = json.load(fp)
-        return round(float(t["closest_bytes_per_ray"]) * rays_per_launch, 1)
-    except (OSError, KeyError, ValueError):
+        return t.get("configs", {}).get(key)
+    except (OSError, ValueError):
         return None
 
 
@@ -79,18 +97,29 @@ def main():
     import torch.distributed as dist
 
     import path_tracing_amd as pta
-    from path_tracing_amd.distributed import reduce_film
+    from path_tracing_amd.distributed import partition_samples, reduce_film
 
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     def note(msg):
         # progress on stderr: big scenes spend minutes before the first kernel
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     W, H, spp = args.width, args.height, args.spp_per_step
+    strong = args.total_spp > 0
     t0 = time.time()
     tris = pta.meshgen.standin_scene(args.level)
     note("mesh of %d triangles generated in %.1f s" % (len(tris), time.time() - t0))
@@ -98,93 +127,156 @@ def main():
     host = pta.HostScene(tris, threads=host_threads(world))
     t_prepare = time.time() - t0
     note("normals, tree and flat arrays in %.1f s" % t_prepare)
-    gpu = pta.GpuScene(host, local_rank)
+    gpu = pta.GpuScene(host, device)
     film_t = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     film = pta.Film(gpu, W, H, external=film_t)
     cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
     lights = pta.cli_lights()
 
+    def reduce_to_rank0():
+        """Canvas::add_from over all workers (canvas.cpp:47-52): one sum-reduce of the film."""
+        if world == 1:
+            return
+        if args.rehearse:
+            h = film_t.cpu()
+            reduce_film(h, dst=0)
+            if rank == 0:
+                film_t.copy_(h)
+        else:
+            reduce_film(film_t, dst=0)
+
+    class Tally:
+        def __init__(self):
+            self.closest = self.shadow = self.traced = self.samples = 0
+
+        def add(self, st):
+            self.closest += st.closest_rays
+            self.shadow += st.shadow_rays
+            self.traced += st.shadow_rays_traced
+            self.samples += st.camera_samples
+
+    def render_range(first, count, tally):
+        done = 0
+        while done < count:
+            take = min(spp, count - done)
+            tally.add(film.render(cam, lights, [(0, 0, -1, -1, first + done, take)], seed=args.seed, want_stats=True))
+            done += take
+
+    def frame(total, base, tally):
+        """One frame of `total` samples per pixel, split over the ranks by sample index."""
+        first, count = partition_samples(total, world, rank)
+        render_range(base + first, count, tally)
+
     total_steps = args.warmup + args.steps
 
-    def step(i):
-        first = (rank * total_steps + i) * spp
-        return film.render(cam, lights, [(0, 0, -1, -1, first, spp)], seed=args.seed, want_stats=True)
+    def step(i, tally):
+        if strong:
+            frame(args.total_spp, i * args.total_spp, tally)
+        else:
+            render_range((rank * total_steps + i) * spp, spp, tally)
 
+    def all_sum(values):
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if world > 1:
+            if not args.rehearse:
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t.cpu()]
+
+    def all_max(value):
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if world > 1:
+            if not args.rehearse:
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.cpu()[0])
+
+    scratch = Tally()
     for i in range(args.warmup):
-        step(i)
+        step(i, scratch)
     gpu.sync()
     note("warm-up done")
-    reduce_film(film_t, dst=0)  # untimed: first use of the collective (communicator, kernels)
+    reduce_to_rank0()  # untimed: first use of the collective (communicator, kernels)
     torch.cuda.synchronize()
     film.zero()
     for c in range(5):
         gpu.kernel_time(c, reset=True)
     gpu.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+
+    # ---- the timed steps ----
+    barrier()
     t_start = time.perf_counter()
-    closest = shadow = samples = traced = 0
+    tally = Tally()
     for i in range(args.warmup, total_steps):
-        st = step(i)
-        closest += st.closest_rays
-        shadow += st.shadow_rays
-        traced += st.shadow_rays_traced
-        samples += st.camera_samples
+        step(i, tally)
     gpu.sync()
-    reduce_film(film_t, dst=0)  # Canvas::add_from over all workers: one RCCL reduce when world > 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-
-    tot = torch.tensor([float(closest), float(shadow), float(samples), float(traced)], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    closest_all, shadow_all, samples_all, traced_all = [float(x) for x in tot.cpu()]
-    elapsed = float(tmax.cpu()[0])
-
+    reduce_to_rank0()
+    barrier()
+    elapsed = all_max(time.perf_counter() - t_start)
+    closest_all, shadow_all, samples_all, traced_all = all_sum([tally.closest, tally.shadow, tally.samples, tally.traced])
     kt = {c: gpu.kernel_time(c) for c in range(5)}
-
+    film_ok = None
     if rank == 0:
-        rays_all = closest_all + shadow_all
-        value = rays_all / elapsed / 1e6
         # sanity of the reduced film: every pixel got every rank's passes
         passes = film_t.view(H, W, 4)[..., 3]
-        expect = float(args.steps * spp * world)
+        expect = float(args.steps * (args.total_spp if strong else spp * world))
         film_ok = bool((passes == expect).all().item())
 
+    # ---- weak mode: the strong-scaling frame (1080p @ 1000 spp on N GPUs), timed on its own ----
+    strong_extra = None
+    if not strong and args.strong_spp > 0:
+        film.zero()
+        gpu.sync()
+        barrier()
+        t1 = time.perf_counter()
+        st = Tally()
+        frame(args.strong_spp, 0, st)
+        gpu.sync()
+        reduce_to_rank0()
+        barrier()
+        wall = all_max(time.perf_counter() - t1)
+        c_all, s_all, n_all, tr_all = all_sum([st.closest, st.shadow, st.samples, st.traced])
+        if rank == 0:
+            ok = bool((film_t.view(H, W, 4)[..., 3] == float(args.strong_spp)).all().item())
+            strong_extra = {"what": "one %dx%d frame of %d samples per pixel, split over the %d rank(s) by sample index, film reduce included"
+                                    % (W, H, args.strong_spp, world),
+                            "wall_s": round(wall, 4), "n_gpus": world, "spp_total": args.strong_spp,
+                            "spp_per_rank": [partition_samples(args.strong_spp, world, r)[1] for r in range(world)],
+                            "camera_samples": int(n_all), "traced_Mrays_per_s": round((c_all + tr_all) / wall / 1e6, 2),
+                            "film_check": ok}
+
+    if rank == 0:
+        rays_ref = closest_all + shadow_all
+        rays_traced = closest_all + traced_all
+        value = rays_traced / elapsed / 1e6
+        std_cfg = (args.level, W, H) == (8, 1920, 1080)
+        per_step = ("%d spp per step split over the ranks" % args.total_spp) if strong else ("%d spp per step per GPU" % spp)
         out = {
             "metric": "Mrays/s (all bounces)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "full path trace (" + ("configs[2]" if (args.level, W, H) == (8, 1920, 1080) else "other scene or size") +
+                "workload": "full path trace (" + ("configs[2]" if std_cfg else "other scene or size") +
                             "): stand-in bumpy icosphere level %d + floor, %d triangles, "
-                            "3 lights, mirror bounces <= 10, DOF 0.1/4.5, %dx%d, %d spp per step per GPU"
-                            % (args.level, host.n, W, H, spp),
-                "triangles": host.n, "width": W, "height": H, "spp_per_step": spp,
-                "parallelism": "sample-partitioned x%d, one RCCL reduce of the film" % world,
+                            "3 lights, mirror bounces <= 10, DOF 0.1/4.5, %dx%d, %s"
+                            % (args.level, host.n, W, H, per_step),
+                "triangles": host.n, "width": W, "height": H, "spp_per_step": args.total_spp if strong else spp,
+                "parallelism": "sample-partitioned x%d, one %s reduce of the film" % (world, "gloo (rehearsal on one GPU)" if args.rehearse else "RCCL"),
             },
+            "ray_counting": "value = rays traced per second (closest-hit casts + shadow rays of light samples with non-zero weight); "
+                            "reference_counted_Mrays_per_s also counts the shadow rays of zero-weight light samples, which the "
+                            "reference casts and this renderer counts but does not trace (same picture bit for bit)",
+            "reference_counted_Mrays_per_s": round(rays_ref / elapsed / 1e6, 2),
             "camera_samples_per_s": round(samples_all / elapsed, 1),
             "wall_s_1080p_1000spp_extrapolated": round(elapsed / samples_all * 1920 * 1080 * 1000, 2),
-            "rays_per_sample": round(rays_all / samples_all, 4),
+            "rays_per_sample": round(rays_ref / samples_all, 4),
             "closest_rays": int(closest_all), "shadow_rays": int(shadow_all), "camera_samples": int(samples_all),
-            # rays are counted as the reference casts them; a shadow ray whose light sample has zero weight
-            # cannot change the picture and is counted but not traced
             "shadow_rays_traced": int(traced_all),
-            "ray_counting": "value counts rays as the reference's rays_cast++ would (closest_rays + shadow_rays); "
-                            "shadow rays of light samples with exactly zero weight are in that count but are not traced "
-                            "(same picture bit for bit) -- traced_Mrays_per_s counts only rays that were traced",
-            "traced_Mrays_per_s": round((closest_all + traced_all) / elapsed / 1e6, 2),
             "film_check": film_ok,
+            "strong_scaling": strong_extra,
             "scene_prepare_s": round(t_prepare, 2),
             "kernel_ms": {name: {"ms": round(kt[c][0], 3), "launches": kt[c][1]} for c, name in
                           enumerate(["closest", "shadow", "generate", "shade", "accumulate"])},
@@ -200,6 +292,7 @@ def main():
             tb = time.time()
             oscene = orc.Scene(tris, threads=threads)
             t_oracle_build = time.time() - tb
+            note("oracle scene in %.1f s" % t_oracle_build)
             ocam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
             # work per ray in the reference's visit order: every 4th 8-row band of the frame, 1 spp
             bands = [(0, y, W, min(8, H - y)) for y in range(0, H, 32)]
@@ -221,8 +314,9 @@ def main():
                 cnt = np.zeros(2, dtype=np.uint64)
                 n_pass = 0
                 tb = time.time()
+                rows = H
                 while True:
-                    _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, None, n_pass, 1, seed=args.seed,
+                    _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, (0, 0, W, rows), n_pass, 1, seed=args.seed,
                                             threads=threads, rgb=rgb, passes=pas)
                     cnt += c
                     n_pass += 1
@@ -233,39 +327,70 @@ def main():
                 cpu = {"value": round(float(cnt.sum()) / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": threads,
                        "kind": "port",
                        "sample": "CPU oracle (strict-IEEE restatement of the reference path), %d threads, %d full "
-                                 "%dx%d passes = %d camera samples in %.2f s; extrapolates to %.0f s per 1000 spp"
+                                 "%dx%d passes = %d camera samples in %.2f s; extrapolates to %.0f s per 1000 spp; rays "
+                                 "counted as the reference casts them"
                                  % (threads, n_pass, W, H, n_samp, t_cpu, t_cpu / n_samp * W * H * 1000),
                        "camera_samples_per_s": round(n_samp / t_cpu, 1),
                        "oracle_scene_build_s": round(t_oracle_build, 2)}
             ms_c, launches_c = kt[0]
             if ms_c > 0 and launches_c > 0:
-                bytes_per_launch = closest / launches_c * b_closest   # rank 0's own launches
-                achieved = bytes_per_launch / (ms_c / launches_c * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(closest / launches_c),
-                        "kernel": "k_trace<closest>",
-                        "note": "achieved prices every box/triangle test of the reference's visit order at HBM cost; the scene "
-                                "(166 MB) sits in L2 + Infinity Cache, so `traffic` (measured HBM-side bytes per launch) is "
-                                "far lower and frac can exceed 1 -- the kernel is bound by the compute units' own vector-memory path (address unit and L1 about 90-98 % busy fetching one 64-byte record per lane and round) together with vector-instruction issue (about 80 %)",
-                        "algorithmic_bytes_per_ray": round(float(b_closest), 1),
-                        "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
-                        "rays_per_launch": round(closest / launches_c, 1),
-                        "avg_launch_ms": round(ms_c / launches_c, 4),
-                        # what the kernel really loads (one 64-byte record per node visit = two box tests, 48 bytes
-                        # per triangle test, the ray) against what the CUs' load path delivers for that access shape
-                        "cu_load_path": {"achieved": round(closest / launches_c * (n_box_c * 32 + n_tri_c * 48 + 24) /
-                                                           (ms_c / launches_c * 1e-3) / 1e9, 2),
-                                         "peak": CU_GATHER_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(closest / launches_c * (n_box_c * 32 + n_tri_c * 48 + 24) /
-                                                       (ms_c / launches_c * 1e-3) / 1e9 / CU_GATHER_PEAK_GBS, 4),
-                                         "peak_source": "scripts/micro/gather_rate.hip: 64 lanes loading their own 64-byte "
-                                                        "records, L2-resident table, whole chip (profiles/r01i_micro_gather_rate.txt)"},
-                        "shadow_kernel": {"algorithmic_bytes_per_ray": round(float(b_shadow), 1),
-                                          "box_tests_per_ray": round(float(n_box_s), 3),
-                                          "tri_tests_per_ray": round(float(n_tri_s), 3),
-                                          "rays_traced": int(traced),
-                                          "achieved": round(traced / max(kt[1][1], 1) * b_shadow /
-                                                            (kt[1][0] / max(kt[1][1], 1) * 1e-3) / 1e9, 2) if kt[1][0] > 0 else None}}
+                closest = tally.closest                       # rank 0's own launches
+                rays_per_launch = closest / launches_c
+                launch_s = ms_c / launches_c * 1e-3
+                algorithmic = rays_per_launch * b_closest / launch_s / 1e9
+                # what the kernel loads into registers: one 64-byte record per node visit (two box tests),
+                # 48 bytes per triangle test, the ray; plus the 16-byte hit it stores
+                loaded_per_ray = n_box_c * 32 + n_tri_c * 48 + 24 + 16
+                loaded = rays_per_launch * loaded_per_ray / launch_s / 1e9
+                scene_bytes = host.flat.n_nodes * 64 + host.n * (48 + 64)
+                key = "level%d_%dx%d" % (args.level, W, H)
+                tr = measured_traffic(key)
+                traffic = round(tr["closest_bytes_per_ray"] * rays_per_launch, 1) if tr else None
+                hbm_meas = None
+                if tr:
+                    g = tr["closest_bytes_per_ray"] * rays_per_launch / launch_s / 1e9
+                    hbm_meas = {"GBps": round(g, 1), "frac_of_hbm_peak": round(g / HBM_PEAK_GBS, 4),
+                                "bytes_per_ray": round(tr["closest_bytes_per_ray"], 1),
+                                "l2_hit_rate": round(tr.get("closest_l2_hit_rate", float("nan")), 4),
+                                "source": "profiles/traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                          "2*FETCH_SIZE + WRITE_SIZE) x this run's rays per second in the kernel" % key}
+                if scene_bytes > INFINITY_CACHE_BYTES:
+                    # the scene streams from HBM: the algorithmic bytes are priced against the HBM peak
+                    roof = {"bound": "hbm", "achieved": round(algorithmic, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(algorithmic / HBM_PEAK_GBS, 5), "traffic": traffic}
+                else:
+                    # the scene (nodes + triangle records) sits in L2 / Infinity Cache: the ceiling that binds is
+                    # the compute units' L2 gather path, priced with the bytes the kernel really loads
+                    roof = {"bound": "l2", "achieved": round(loaded, 2), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(loaded / L2_GATHER_PEAK_GBS, 5), "traffic": traffic,
+                            "peak_sources": {"hardware_guide_l2_resident_row_gather_GBps": [16800.0, 18800.0],
+                                             "hardware_guide_l2_aggregate_GBps": 34500.0,
+                                             "own_microbenchmark_64B_per_lane_records_GBps": OWN_GATHER_RATE_GBS,
+                                             "own_microbenchmark_source": "scripts/micro/gather_rate.hip, profiles/r01i_micro_gather_rate.txt"},
+                            "frac_of_own_microbenchmark": round(loaded / OWN_GATHER_RATE_GBS, 4)}
+                roof.update({
+                    "kernel": "k_trace<closest>",
+                    "scene_bytes": int(scene_bytes),
+                    "loaded_bytes_per_ray": round(float(loaded_per_ray), 1),
+                    "loaded_GBps": round(loaded, 2),
+                    "algorithmic_bytes_per_ray": round(float(b_closest), 1),
+                    "algorithmic_GBps": round(algorithmic, 2),
+                    "algorithmic_over_hbm_peak": round(algorithmic / HBM_PEAK_GBS, 4),
+                    "algorithmic_note": "every box and triangle test of the reference's visit order priced at its record's bytes; "
+                                        "it exceeds what reaches HBM when the scene is cache-resident (see hbm_measured), so it is a "
+                                        "ratio, not a fraction of a roofline",
+                    "hbm_measured": hbm_meas,
+                    "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
+                    "rays_per_launch": round(rays_per_launch, 1),
+                    "avg_launch_ms": round(ms_c / launches_c, 4),
+                    "shadow_kernel": {"algorithmic_bytes_per_ray": round(float(b_shadow), 1),
+                                      "box_tests_per_ray": round(float(n_box_s), 3),
+                                      "tri_tests_per_ray": round(float(n_tri_s), 3),
+                                      "rays_traced": int(tally.traced),
+                                      "algorithmic_GBps": round(tally.traced / max(kt[1][1], 1) * b_shadow /
+                                                                (kt[1][0] / max(kt[1][1], 1) * 1e-3) / 1e9, 2) if kt[1][0] > 0 else None,
+                                      "hbm_measured_bytes_per_ray": round(tr["shadow_bytes_per_ray"], 1) if tr and "shadow_bytes_per_ray" in tr else None,
+                                      "l2_hit_rate": round(tr["shadow_l2_hit_rate"], 4) if tr and "shadow_l2_hit_rate" in tr else None}})
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

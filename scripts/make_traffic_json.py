@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Derives profiles/traffic.json from a scripts/profile_round.sh output directory.
 
+    python scripts/make_traffic_json.py <dir> [<workload key> [<traffic.json to merge into>]] > new.json
+
+The file holds one entry per workload ("level8_1920x1080", "level10_3840x2160", ...), which is
+how bench.py looks its own workload up.
+
 HBM-side bytes of the closest-hit trace kernel per ray = (2 * FETCH_SIZE + WRITE_SIZE) / rays,
 where FETCH_SIZE and WRITE_SIZE are the rocprofv3 counters (kilobytes) summed over every
 dispatch of k_trace<1> in their own PMC passes, FETCH_SIZE doubled as the gfx950 correction for
@@ -30,6 +35,8 @@ def counter_sum(root, counter, kernel):
 
 def main():
     root = sys.argv[1]
+    key = sys.argv[2] if len(sys.argv) > 2 else "level8_1920x1080"   # workload the passes were run on
+    merge_into = sys.argv[3] if len(sys.argv) > 3 else None            # existing traffic.json to update
     # the PMC passes run `bench.py --steps 2 --warmup 1`; their own bench line gives the ray counts
     name = "bench_line_under_pmc.json" if os.path.exists(os.path.join(root, "bench_line_under_pmc.json")) else "bench_line_under_profiler.json"
     line = json.loads(open(os.path.join(root, name)).read().strip().splitlines()[-1])
@@ -51,7 +58,11 @@ def main():
         out[name + "_bytes_per_ray"] = (2.0 * fetch_kb + write_kb) * 1024.0 / rays
         if hit and miss:
             out[name + "_l2_hit_rate"] = hit / (hit + miss)
-    print(json.dumps(out, indent=1))
+    doc = {"configs": {}}
+    if merge_into and os.path.exists(merge_into):
+        doc = json.load(open(merge_into))
+    doc.setdefault("configs", {})[key] = out
+    print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":

@@ -5,14 +5,15 @@
 #      beyond --kernel-trace): HBM-side traffic (FETCH_SIZE, WRITE_SIZE), L2 hit rate, SQ busy/
 #      wait/VALU counters, L1 counters;
 #   3. text summaries via scripts/rocpd_summary.py and profiles/traffic.json for bench.py.
-# Usage: bash scripts/profile_round.sh <tag>
+# Usage: bash scripts/profile_round.sh <tag> ["extra bench.py flags"]
 set -u
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -o bench -- python3 bench.py > $OUT/bench_stats.log 2>&1 || { echo "kernel trace failed"; exit 1; }
+EXTRA=${2:-}
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --strong-spp 0 $EXTRA"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -o bench -- python3 bench.py $EXTRA > $OUT/bench_stats.log 2>&1 || { echo "kernel trace failed"; exit 1; }
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
