@@ -441,16 +441,54 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
 
 struct DLight { V3f pos, color; };
 
-/* One entry of a batch: n_samples consecutive samples of one rectangle.  Paths of the entry
- * are numbered path0 + s*padded + q, q walking the rectangle in 8x8 pixel blocks so that the
- * 64 lanes of a wave start out as a compact screen tile. */
+/* One entry of a batch: n_samples consecutive samples of one rectangle.  The rectangle is cut
+ * into 8x8-pixel blocks (`padded` = 64 * blocks path slots per sample) and every block into
+ * square units of side 2^side_log2 pixels (8x8, 4x4, 2x2 or single pixels).  Paths are numbered
+ * unit by unit, inside a unit sample by sample, the unit's pixels innermost:
+ *     path0 + (unit * n_samples + s) * pixels_per_unit + pixel_in_unit
+ * so the 64 lanes of a wave start out as a few samples of one small screen patch, and
+ * consecutive waves -- which run at the same time, on the same XCD -- work on the SAME patch: they
+ * walk the same part of the tree and find its records in L1/L2.  (Numbering sample by sample
+ * instead, every pixel of sample s before any of sample s+1, sends each wave's neighbours to
+ * other parts of the screen.)  The film sums a pixel's samples in sample order whatever the
+ * numbering, so the picture does not depend on it. */
 struct SubPass {
     int32_t x, y, w, h;
     uint32_t first_sample, n_samples;
     uint32_t blocks_x, padded; /* ceil(w/8); 64*ceil(w/8)*ceil(h/8) */
     uint32_t path0;
     uint32_t group_first;      /* first entry in the batch with the same rectangle */
+    uint32_t side_log2;        /* 0..3: units of 1, 2x2, 4x4, 8x8 pixels */
+    uint32_t pad;
 };
+
+/* Where path `local` (0 .. padded*n_samples-1) of an entry sits: its sample number within the
+ * entry and its slot q = block*64 + ly*8 + lx among the entry's padded pixels. */
+__device__ __forceinline__ void path_to_pixel(const SubPass& s, uint32_t local, uint32_t& si, uint32_t& q) {
+    const uint32_t sl = s.side_log2, P = 1u << (2u * sl);
+    const uint32_t per_unit = s.n_samples << (2u * sl);
+    const uint32_t unit = local / per_unit, rem = local - unit * per_unit;
+    si = rem >> (2u * sl);
+    const uint32_t pix = rem & (P - 1u);
+    const uint32_t units_log2 = 6u - 2u * sl;                    /* units per 8x8 block, log2 */
+    const uint32_t blk = unit >> units_log2, sub = unit & ((1u << units_log2) - 1u);
+    const uint32_t row_log2 = 3u - sl;                           /* units per block row, log2 */
+    const uint32_t lx = ((sub & ((1u << row_log2) - 1u)) << sl) + (pix & ((1u << sl) - 1u));
+    const uint32_t ly = ((sub >> row_log2) << sl) + (pix >> sl);
+    q = (blk << 6) + (ly << 3) + lx;
+}
+
+/* The inverse for one pixel slot: path of sample si is base + si * stride. */
+__device__ __forceinline__ void pixel_to_path(const SubPass& s, uint32_t q, uint32_t& base, uint32_t& stride) {
+    const uint32_t sl = s.side_log2;
+    const uint32_t blk = q >> 6, lx = q & 7u, ly = (q >> 3) & 7u;
+    const uint32_t row_log2 = 3u - sl, units_log2 = 6u - 2u * sl;
+    const uint32_t sub = ((ly >> sl) << row_log2) + (lx >> sl);
+    const uint32_t pix = ((ly & ((1u << sl) - 1u)) << sl) + (lx & ((1u << sl) - 1u));
+    const uint32_t unit = (blk << units_log2) + sub;
+    stride = 1u << (2u * sl);
+    base = s.path0 + ((unit * s.n_samples) << (2u * sl)) + pix;
+}
 
 struct RenderBuffers {
     /* two ray queues (current / next) */
@@ -499,6 +537,10 @@ __device__ __forceinline__ uint32_t find_subpass(const SubPass* sp, uint32_t n_s
 #ifndef STREAM_BLOCK
 #define STREAM_BLOCK 512
 #endif
+#ifndef PATH_UNIT_SIDE_LOG2
+#define PATH_UNIT_SIDE_LOG2 2u  /* default side of a path-numbering unit: 2^2 = 4 pixels (8 / 4 / 2 / 1 on the full render:
+                                   5 590 / 5 627 / 5 621 / 5 230 Mrays/s; sample-major numbering before: 5 558) */
+#endif
 
 /* Workgroup-wide stream compaction: every thread calls it; threads with `flag` get distinct
  * consecutive slots starting at a base taken from *counter with ONE atomic per workgroup (a
@@ -545,8 +587,8 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_generate(CamParams cam, const 
         if (p64 < n_paths) {
             const uint32_t p = (uint32_t)p64;
             const SubPass s = sp[find_subpass(sp, n_sp, p)];
-            uint32_t local = p - s.path0;
-            uint32_t si = local / s.padded, q = local - si * s.padded;
+            uint32_t si, q;
+            path_to_pixel(s, p - s.path0, si, q);
             uint32_t blk = q >> 6, lx = q & 7u, ly = (q >> 3) & 7u;
             int bx = (int)(blk % s.blocks_x), by = (int)(blk / s.blocks_x);
             int rx = bx * 8 + (int)lx, ry = by * 8 + (int)ly;
@@ -758,28 +800,29 @@ __global__ __launch_bounds__(256) void k_accumulate(uint32_t n_lights, uint32_t 
 }
 
 /* Adds finished paths to the film: one thread per pixel of each rectangle group, walking the
- * group's entries and their samples in order, so sums do not depend on scheduling. */
-__global__ __launch_bounds__(256) void k_film(const SubPass* sp, uint32_t n_sp, const uint32_t* group_entry,
-                                               const uint32_t* group_off, uint32_t n_groups, uint32_t total,
+ * group's entries (entry_list[entry_off[g] .. entry_off[g+1])) and their samples in order, so sums
+ * do not depend on scheduling or on how paths are numbered. */
+__global__ __launch_bounds__(256) void k_film(const SubPass* sp, const uint32_t* group_off, const uint32_t* entry_off,
+                                               const uint32_t* entry_list, uint32_t n_groups, uint32_t total,
                                                int width, float4* film, RenderBuffers b) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
     /* group g owns threads [group_off[g], group_off[g+1]) */
     uint32_t lo = 0, hi = n_groups;
     while (lo + 1 < hi) { uint32_t mid = (lo + hi) >> 1; if (group_off[mid] <= k) lo = mid; else hi = mid; }
-    uint32_t first = group_entry[lo];
-    const SubPass s0 = sp[first];
+    const uint32_t e0 = entry_off[lo], e1 = entry_off[lo + 1];
+    const SubPass s0 = sp[entry_list[e0]];
     uint32_t q = k - group_off[lo];
     uint32_t blk = q >> 6, lx = q & 7u, ly = (q >> 3) & 7u;
     int rx = (int)(blk % s0.blocks_x) * 8 + (int)lx, ry = (int)(blk / s0.blocks_x) * 8 + (int)ly;
     if (rx >= s0.w || ry >= s0.h) return;
     size_t pix = (size_t)(s0.y + ry) * (size_t)width + (size_t)(s0.x + rx);
     float4 acc = film[pix];
-    for (uint32_t e = first; e < n_sp; e++) {
-        if (sp[e].group_first != first) continue;
-        const SubPass s = sp[e];
-        for (uint32_t si = 0; si < s.n_samples; si++) {
-            uint32_t p = s.path0 + si * s.padded + q;
+    for (uint32_t e = e0; e < e1; e++) {
+        const SubPass s = sp[entry_list[e]];
+        uint32_t p, stride;
+        pixel_to_path(s, q, p, stride);
+        for (uint32_t si = 0; si < s.n_samples; si++, p += stride) {
             acc.x += b.rad_r[p]; acc.y += b.rad_g[p]; acc.z += b.rad_b[p];
             acc.w += 1.0f;
         }
@@ -1277,7 +1320,7 @@ struct RenderLane {
     RenderBuffers rb{};
     DLight* d_lights = nullptr;
     SubPass* d_sub = nullptr;
-    uint32_t* d_groups = nullptr; /* group_entry[cap] then group_off[cap+1] */
+    uint32_t* d_groups = nullptr; /* group_off[cap+1], entry_off[cap+1], entry_list[cap] */
     size_t cap_sub = 0;
     uint32_t* h_cnt = nullptr;    /* pinned: the batch's counters */
     hipEvent_t film_done = nullptr;
@@ -1371,7 +1414,7 @@ static int lane_ensure_scratch(RenderLane* f, size_t paths, uint32_t n_lights, s
     if (!rc) rc = film_alloc(f, &b.cnt, (size_t)CNT_WORDS);
     if (!rc) rc = film_alloc(f, &f->d_lights, (size_t)PT_MAX_LIGHTS);
     if (!rc) rc = film_alloc(f, &f->d_sub, G);
-    if (!rc) rc = film_alloc(f, &f->d_groups, 2 * G + 2);
+    if (!rc) rc = film_alloc(f, &f->d_groups, 3 * G + 2);
     if (rc) { lane_free_scratch(f); return rc; }
     f->cap_paths = P; f->cap_lights = L; f->cap_sub = G;
     return PT_OK;
@@ -1400,17 +1443,33 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
     RenderBuffers& b = ln.rb;
     hipStream_t st = ctx.stream;
     const std::vector<SubPass>& sub = ln.h_sub;
-    /* rectangle groups for the film kernel */
-    std::vector<uint32_t>&g_entry = ln.h_entry, &g_off = ln.h_off;
-    g_entry.clear(); g_off.clear();
+    /* rectangle groups for the film kernel: per group its thread range and the list of its entries
+     * in batch order.  d_groups holds group_off[cap+1], entry_off[cap+1], entry_list[cap]. */
+    std::vector<uint32_t>&g_off = ln.h_off, &g_entry = ln.h_entry;
+    const uint32_t n_sub = (uint32_t)sub.size();
+    g_off.clear();
+    std::vector<uint32_t> group_of(n_sub), count;
     uint32_t total = 0;
-    for (uint32_t e = 0; e < sub.size(); e++)
-        if (sub[e].group_first == e) { g_entry.push_back(e); g_off.push_back(total); total += sub[e].padded; }
+    for (uint32_t e = 0; e < n_sub; e++) {
+        if (sub[e].group_first == e) { group_of[e] = (uint32_t)count.size(); count.push_back(0); g_off.push_back(total); total += sub[e].padded; }
+        else group_of[e] = group_of[sub[e].group_first];
+        count[group_of[e]]++;
+    }
     g_off.push_back(total);
-    uint32_t n_groups = (uint32_t)g_entry.size();
+    const uint32_t n_groups = (uint32_t)count.size();
+    g_entry.assign((size_t)n_groups + 1 + n_sub, 0);          /* entry_off then entry_list */
+    for (uint32_t g = 0; g < n_groups; g++) g_entry[g + 1] = g_entry[g] + count[g];
+    {
+        std::vector<uint32_t> fill(g_entry.begin(), g_entry.begin() + n_groups);
+        for (uint32_t e = 0; e < n_sub; e++) g_entry[(size_t)n_groups + 1 + fill[group_of[e]]++] = e;
+    }
+    uint32_t* d_group_off = ln.d_groups;
+    uint32_t* d_entry_off = ln.d_groups + ln.cap_sub + 1;
+    uint32_t* d_entry_list = ln.d_groups + 2 * (ln.cap_sub + 1);
     HIP_TRY(hipMemcpyAsync(ln.d_sub, sub.data(), sub.size() * sizeof(SubPass), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ln.d_groups, g_entry.data(), n_groups * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ln.d_groups + ln.cap_sub, g_off.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_group_off, g_off.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_entry_off, g_entry.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_entry_list, g_entry.data() + n_groups + 1, n_sub * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, st));
     {
         ScopedTimer tm(s, PT_KERNEL_GENERATE, st);
@@ -1469,8 +1528,8 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
     if (after) HIP_TRY(hipStreamWaitEvent(st, after, 0));
     {
         ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
-        hipLaunchKernelGGL(k_film, dim3((total + 255) / 256), dim3(256), 0, st, ln.d_sub, (uint32_t)sub.size(), ln.d_groups,
-                           ln.d_groups + ln.cap_sub, n_groups, total, f->width, f->d_film, b);
+        hipLaunchKernelGGL(k_film, dim3((total + 255) / 256), dim3(256), 0, st, ln.d_sub, d_group_off, d_entry_off, d_entry_list,
+                           n_groups, total, f->width, f->d_film, b);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ln.film_done, st));
@@ -1752,6 +1811,9 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         pt_film* f; LaunchCtx* ctx;
         ~Drain() { for (int li = 0; li < RENDER_LANES; li++) if (f->lane[li].in_flight) { (void)hipStreamSynchronize(ctx[li].stream); f->lane[li].in_flight = false; } }
     } drain{f, ctx};
+    /* PT_PATH_UNIT = 1, 2, 4 or 8: side of the screen patch whose samples are numbered together (see SubPass) */
+    uint32_t unit_side_log2 = PATH_UNIT_SIDE_LOG2;
+    if (const char* e = getenv("PT_PATH_UNIT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) unit_side_log2 = v == 1 ? 0u : v == 2 ? 1u : v == 4 ? 2u : 3u; }
     std::vector<SubPass> batch;
     size_t batch_paths = 0;
     int next_lane = 0;
@@ -1793,6 +1855,7 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
             sp.x = p.x; sp.y = p.y; sp.w = p.w; sp.h = p.h;
             sp.first_sample = p.first_sample + done; sp.n_samples = take;
             sp.blocks_x = c.bx; sp.padded = (uint32_t)padded; sp.path0 = (uint32_t)batch_paths;
+            sp.side_log2 = unit_side_log2;
             sp.group_first = (uint32_t)batch.size();
             for (uint32_t e = 0; e < batch.size(); e++)
                 if (batch[e].x == p.x && batch[e].y == p.y && batch[e].w == p.w && batch[e].h == p.h) { sp.group_first = batch[e].group_first; break; }

@@ -2,7 +2,9 @@
 """Micro-benchmark of the trace kernels alone (BASELINE.json configs[1] and an incoherent set).
 
 Rays are resident in HBM; time is the kernels' own (HIP events on the library's stream).
-    python scripts/raycast_bench.py [--level 8] [--reps 5] [--sets primary,bounce,sphere,shadow]
+    python scripts/raycast_bench.py [--level 8] [--reps 5] [--sets primary,bounce,sphere,shadow,binned]
+"binned" adds, for every incoherent set, the same rays ordered by direction octant and Morton cell
+of the origin (and shuffled), to price what a ray-binning pass could buy.
 """
 import argparse
 import ctypes as C
@@ -114,6 +116,48 @@ def main():
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         rays = soa(o.astype(np.float32)) + soa(d.astype(np.float32))
         run_closest("incoherent_sphere", rays)
+    def binned(rays):
+        """The same rays ordered by direction octant, then by a 30-bit Morton code of the origin's
+        cell in a 1024^3 grid over the rays' bounding box: what a binning pass ahead of the trace
+        kernel could deliver at best."""
+        o = torch.stack(rays[:3], dim=1)
+        d = torch.stack(rays[3:], dim=1)
+        lo, hi = o.min(dim=0).values, o.max(dim=0).values
+        cell = ((o - lo) / (hi - lo).clamp_min(1e-20) * 1023.0).clamp(0, 1023).to(torch.int64)
+
+        def spread(x):
+            x = (x | (x << 16)) & 0x030000FF
+            x = (x | (x << 8)) & 0x0300F00F
+            x = (x | (x << 4)) & 0x030C30C3
+            x = (x | (x << 2)) & 0x09249249
+            return x
+        morton = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
+        octant = (d[:, 0] < 0).to(torch.int64) | ((d[:, 1] < 0).to(torch.int64) << 1) | ((d[:, 2] < 0).to(torch.int64) << 2)
+        order = torch.argsort((octant << 30) | morton)
+        return [r[order].contiguous() for r in rays]
+
+    if "sphere" in sets and "binned" in sets:
+        run_closest("incoherent_sphere_binned", binned(rays))
+    if "bounce" in sets:
+        # mirror-bounce rays off the primary hits (geometric normal), in screen order and binned
+        idx, t, u, v = run_closest("primary_for_bounce", prim)
+        hit = idx >= 0
+        nrm = torch.from_numpy(np.ascontiguousarray(host.triangle_data()[:, 15:18])).to(dev)[idx[hit].long()]
+        dd = torch.stack([prim[3 + k][hit] for k in range(3)], dim=1)
+        oo = torch.stack([prim[k][hit] + t[hit] * prim[3 + k][hit] for k in range(3)], dim=1)
+        nd = (nrm * dd).sum(dim=1, keepdim=True)
+        nrm = torch.where(nd > 0, -nrm, nrm)
+        refl = dd - 2.0 * (nrm * dd).sum(dim=1, keepdim=True) * nrm
+        refl = refl / refl.norm(dim=1, keepdim=True)
+        oo = oo + 1e-3 * nrm
+        brays = [oo[:, k].contiguous() for k in range(3)] + [refl[:, k].contiguous() for k in range(3)]
+        run_closest("bounce_screen_order", brays)
+        # a second bounce: far less coherent than the first
+        idx2, t2, _, _ = run_closest("bounce_screen_order", brays)
+        if "binned" in sets:
+            run_closest("bounce_binned", binned(brays))
+        perm = torch.randperm(brays[0].numel(), device=dev)
+        run_closest("bounce_shuffled", [r[perm].contiguous() for r in brays])
     if "shadow" in sets:
         # shadow-like rays: from primary hit points toward the first light
         idx, t, u, v = run_closest("primary_again", prim) if "primary" not in sets else out
@@ -139,6 +183,17 @@ def main():
         res["shadow_to_light0"] = {"rays": m, "ms_per_call": round(ms / args.reps, 4),
                                    "Mrays_s": round(m / (ms / args.reps) / 1e3, 1),
                                    "visible_fraction": round(float((vis == 1).float().mean().item()), 4)}
+        if "binned" in sets:
+            perm = torch.randperm(m, device=dev)
+            for name, rr, dd2 in (("shadow_to_light0_shuffled", [r[perm].contiguous() for r in rays], distc[perm].contiguous()),):
+                gpu.raycast_shadow_dev(rr, dd2, vis)
+                gpu.sync()
+                gpu.kernel_time(1, reset=True)
+                for _ in range(args.reps):
+                    gpu.raycast_shadow_dev(rr, dd2, vis)
+                gpu.sync()
+                ms, launches = gpu.kernel_time(1, reset=True)
+                res[name] = {"rays": m, "ms_per_call": round(ms / args.reps, 4), "Mrays_s": round(m / (ms / args.reps) / 1e3, 1)}
     print(json.dumps(res))
 
 
