@@ -87,6 +87,10 @@ typedef struct pt_flat_scene {
 typedef struct pt_scene pt_scene;
 
 int  pt_device_count(int* n);
+/* Brings up the runtime's context on a device ahead of the first scene on it (a few tenths of a
+ * second on a cold process), so that a host program can do it on a spare thread while it still
+ * reads and builds its scene.  Optional: pt_scene_create does the same implicitly. */
+int  pt_device_prepare(int device);
 /* Uploads the flattened tree; immutable afterwards.  Replaces the device-less
  * `new kdTree(mesh)` result that Scene holds (integrator.cpp:30).  The arrays are checked
  * (child references in range, depth <= PT_MAX_TREE_DEPTH, leaf ranges inside the triangle
@@ -101,13 +105,22 @@ void pt_scene_destroy(pt_scene* s);
  * Directions are used as given (the reference normalises in Ray's constructor, not here).
  * tri_index = mesh triangle index or -1; t,u,v are 0 on a miss.  Visit order, tie-breaking
  * and arithmetic follow kdTreeNode::ray_test (kdtree.cpp:271-396) exactly.
- * Host-pointer form: arrays of n floats each, copied to and from the device. */
+ * Host-pointer form: arrays of n floats each, copied to and from the device.  Calls with
+ * n <= 64 (one ray under the mouse, kdTree::ray_test) go through a pinned block that the kernel
+ * reads and writes directly, on a stream of their own behind a lock inside the handle: they
+ * allocate nothing after the first one and may be made while another thread renders or casts with
+ * the same scene (the one exception to the one-thread-per-handle rule). */
 int pt_raycast_closest(pt_scene* s, uint64_t n,
                        const float* ox, const float* oy, const float* oz,
                        const float* dx, const float* dy, const float* dz,
                        int32_t* tri_index, float* t, float* u, float* v);
 /* Device-pointer form (inputs and outputs already resident in HBM); asynchronous on the
- * scene's stream, ordered after earlier calls on the same scene; pt_scene_sync() waits. */
+ * scene's stream, ordered after earlier calls on the same scene; pt_scene_sync() waits.
+ * The scene's stream is private to the handle (created non-blocking) and is NOT ordered after any
+ * stream of the caller: whatever produces the inputs must have finished (a device or stream
+ * synchronisation, or an event the caller has waited for) before a *_dev entry point is called,
+ * and the outputs may be consumed on other streams only after pt_scene_sync().  The same holds
+ * for a film created on a caller's buffer (pt_film_create with d_external). */
 int pt_raycast_closest_dev(pt_scene* s, uint64_t n,
                            const float* d_ox, const float* d_oy, const float* d_oz,
                            const float* d_dx, const float* d_dy, const float* d_dz,
@@ -251,8 +264,9 @@ int  pt_films_reduce(pt_film* const* films, int n, float* rgb_sum, int32_t* per_
 int  pt_film_add(pt_film* f, const float* rgb_sum, const int32_t* per_pixel_passes);
 
 /* Integrator::perform_pass (integrator.cpp:211-275) for every listed tile pass, as a
- * wavefront path tracer.  Asynchronous unless stats != NULL (then it waits and fills stats).
- * Pixels touched by several entries are accumulated in list order. */
+ * wavefront path tracer.  The call returns when the passes have been rendered into the film
+ * (it waits for its last batch's counters); stats, if not NULL, receives the ray counts and the
+ * GPU time.  Pixels touched by several entries are accumulated in list order. */
 int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, int n_lights,
                      const pt_tile_pass* passes, int n_passes, uint64_t seed,
                      pt_render_stats* stats);

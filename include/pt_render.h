@@ -107,16 +107,21 @@ class kdTree { /* kdtree.h:64-85 */
     friend struct Scene;
     friend struct RenderEngine;
     friend struct Integrator;
+    friend struct RenderThread;
     std::vector<Triangle>* all_triangles;
     pth_scene* built;                 /* mesh, tree and flattened arrays on the host */
     std::vector<pt_scene*> on_device; /* uploaded lazily, one per GPU */
+    std::vector<pthread_mutex_t*> device_mutex; /* one per uploaded scene: a pt_scene is driven by one thread at a time */
     pthread_mutex_t lock;
     kdTree(std::vector<Triangle>* all_triangles, pth_scene* prebuilt); /* adopts a finished build */
+    void lock_device(int device);
+    void unlock_device(int device);
 public:
     kdTreeNode* root;
     kdTree(std::vector<Triangle>* all_triangles); /* builds from the triangles' corner points */
     ~kdTree();
-    /* Closest hit of one ray, as a one-ray batch on GPU 0.  Outputs are written only on a hit. */
+    /* Closest hit of one ray, as a one-ray batch on GPU 0.  Outputs are written only on a hit.
+     * As in the reference, it may be called from any thread while workers render. */
     bool ray_test(const Ray& ray, Real& hit_parameter, Real& hit_u, Real& hit_v, const Triangle** hit_triangle = nullptr);
     pt_scene* device_scene(int device); /* NULL on failure; pt_last_error() has the reason */
 };
@@ -172,7 +177,9 @@ public:
 
 struct RenderEngine;
 
-struct Integrator { /* integrator.h:45-60; renders on one GPU */
+/* integrator.h:45-60; renders on one GPU.  Several Integrators (the engine's worker of that GPU
+ * among them) may share a GPU: their render calls take turns on that GPU's scene. */
+struct Integrator {
     Scene* scene;
     Canvas* canvas;   /* host copy of the film, refreshed by perform_pass / download() */
     int passes;
@@ -191,7 +198,8 @@ struct Integrator { /* integrator.h:45-60; renders on one GPU */
 struct RenderMessage {
     bool do_die;
     PassDescriptor desc;
-    uint32_t sample; /* index in the random stream: the n-th pass issued for this rectangle */
+    uint32_t sample; /* index in the random stream of the first pass of the run */
+    uint32_t count;  /* passes of this rectangle in the run, with consecutive sample indices */
 };
 
 struct RenderThread { /* integrator.h:67-89: one per GPU */
@@ -229,12 +237,27 @@ struct RenderEngine { /* integrator.h:91-127 */
     RenderEngine(int width, int height, Scene* scene);
     ~RenderEngine();
     void issue_pass_desc(PassDescriptor desc);
+    /* `count` passes of one rectangle as ONE queue entry (perform_full_passes issues a tile's
+     * passes this way: half a million queue entries for 1000 samples of a 1080p frame would cost
+     * more host time than the GPUs need for a tenth of the render) */
+    void issue_pass_run(PassDescriptor desc, int count);
     void perform_full_pass();
     void perform_full_passes(int pass_count);
     void sync();
     void kill_workers();
+    /* Sums the workers' films into master_canvas and returns the number of passes in it, or -1 if
+     * the films could not be summed (then master_canvas is zero and last_error says why). */
     int rebuild_master_canvas();
     void zero();
+    /* What went wrong, if anything: render calls that failed on a GPU (their passes are counted as
+     * completed so that sync() and the progress bar end, but they are not in the picture), and the
+     * way the last rebuild_master_canvas summed the films ("rccl", "host", or "host after rccl
+     * failed").  Front ends check render_errors after sync() and exit non-zero. */
+    int render_errors;
+    std::string last_error;
+    std::string last_reduce_how;
+    uint32_t next_global_sample; /* see issue_pass_desc */
+    bool mixed_rectangles;
     /* Continues a render: zero(), then the canvas' accumulators become the first worker's film
      * and every rectangle's sample stream starts after the samples the canvas already holds
      * (its largest pass count).  0 on success. */

@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -893,6 +894,16 @@ struct pt_scene {
     uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, two sets of queue heads at SMALL_HEADS0/1 */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
     uint32_t* d_static_scratch = nullptr; /* this device's copy of `scratch` (never allocated, never freed) */
+    /* Small host-pointer casts (pt_raycast_closest with n <= PICK_MAX_RAYS: one ray under the mouse,
+     * kdTree::ray_test): their own stream, counters, spill area and a pinned host block that the
+     * kernel reads the rays from and writes the hits to, made on first use and kept, behind a
+     * mutex -- so such a call needs no allocation, no copy, and may run while another thread
+     * renders with this scene. */
+    std::mutex pick_mu;
+    hipStream_t pick_stream = nullptr;
+    uint32_t* d_pick = nullptr;   /* PICK_HEAD_WORDS of counters, then the spill area of PICK_GRID workgroups */
+    float* h_pick = nullptr;      /* pinned, device-visible: 10 arrays of PICK_MAX_RAYS words */
+    float* h_pick_dev = nullptr;  /* the same block as the GPU addresses it */
     /* second render lane (see pt_render_passes): its own stream and spill area, made on first use */
     hipStream_t stream2 = nullptr;
     uint32_t* d_spill2 = nullptr;
@@ -1005,6 +1016,15 @@ int pt_device_count(int* n) {
     return PT_OK;
 }
 
+int pt_device_prepare(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= count) return fail(PT_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));   /* forces the context into existence */
+    return PT_OK;
+}
+
 int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     if (!flat || !out) return fail(PT_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1066,6 +1086,9 @@ void pt_scene_destroy(pt_scene* s) {
     if (s->d_spill) (void)hipFree(s->d_spill);
     if (s->d_spill2) (void)hipFree(s->d_spill2);
     if (s->d_defer) (void)hipFree(s->d_defer);
+    if (s->pick_stream) { (void)hipStreamSynchronize(s->pick_stream); (void)hipStreamDestroy(s->pick_stream); }
+    if (s->d_pick) (void)hipFree(s->d_pick);
+    if (s->h_pick) (void)hipHostFree(s->h_pick);
     if (s->ev_order) (void)hipEventDestroy(s->ev_order);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1248,6 +1271,36 @@ struct DevBuf {
 
 extern "C" {
 
+/* Up to PICK_MAX_RAYS rays from host arrays: see pt_scene::pick_mu. */
+#define PICK_MAX_RAYS 64u
+#define PICK_GRID 8u
+#define PICK_HEAD_WORDS 256u
+static int raycast_closest_small(pt_scene* s, uint32_t n, const float* const* in6, int32_t* idx, float* t, float* u, float* v) {
+    std::lock_guard<std::mutex> guard(s->pick_mu);
+    if (!s->pick_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->pick_stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void**)&s->d_pick, (PICK_HEAD_WORDS + (size_t)PICK_GRID * TRACE_BLOCK * (STACK_MAX_CLOSEST - STACK_LDS)) * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void**)&s->h_pick, 10 * PICK_MAX_RAYS * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&s->h_pick_dev, s->h_pick, 0));
+    }
+    float* h = s->h_pick;
+    for (int k = 0; k < 6; k++) memcpy(h + k * PICK_MAX_RAYS, in6[k], n * sizeof(float));
+    float* d = s->h_pick_dev;
+    hipLaunchKernelGGL(k_noalloc_prepare, dim3(1), dim3(PICK_HEAD_WORDS), 0, s->pick_stream, s->d_pick, n);
+    HIP_TRY(hipGetLastError());
+    TraceArgs a{};
+    a.rays = {d, d + PICK_MAX_RAYS, d + 2 * PICK_MAX_RAYS, d + 3 * PICK_MAX_RAYS, d + 4 * PICK_MAX_RAYS, d + 5 * PICK_MAX_RAYS};
+    a.d_count = s->d_pick; a.count_mul = 1; a.d_next_chunk = s->d_pick + SMALL_HEADS0;
+    a.out_idx = (int32_t*)(d + 6 * PICK_MAX_RAYS); a.out_t = d + 7 * PICK_MAX_RAYS; a.out_u = d + 8 * PICK_MAX_RAYS; a.out_v = d + 9 * PICK_MAX_RAYS;
+    a.spill = s->d_pick + PICK_HEAD_WORDS;
+    hipLaunchKernelGGL(k_trace<TRACE_CLOSEST_MESH>, dim3(PICK_GRID), dim3(TRACE_BLOCK), 0, s->pick_stream, s->d, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->pick_stream));
+    memcpy(idx, h + 6 * PICK_MAX_RAYS, n * 4); memcpy(t, h + 7 * PICK_MAX_RAYS, n * 4);
+    memcpy(u, h + 8 * PICK_MAX_RAYS, n * 4); memcpy(v, h + 9 * PICK_MAX_RAYS, n * 4);
+    return PT_OK;
+}
+
 int pt_raycast_closest(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                        const float* dy, const float* dz, int32_t* idx, float* t, float* u, float* v) {
     if (!s) return fail(PT_ERR_INVALID, "null scene");
@@ -1255,6 +1308,10 @@ int pt_raycast_closest(pt_scene* s, uint64_t n, const float* ox, const float* oy
     if (!ox || !oy || !oz || !dx || !dy || !dz || !idx || !t || !u || !v) return fail(PT_ERR_INVALID, "null array");
     int rc = set_device(s);
     if (rc) return rc;
+    if (n <= PICK_MAX_RAYS && s->n_tris > 0) {
+        const float* in6[6] = {ox, oy, oz, dx, dy, dz};
+        return raycast_closest_small(s, (uint32_t)n, in6, idx, t, u, v);
+    }
     DevBuf in[6], out[4];
     const float* src[6] = {ox, oy, oz, dx, dy, dz};
     for (int k = 0; k < 6; k++) {

@@ -84,7 +84,8 @@ int main(int argc, char** argv) {
 
         engine->perform_full_passes(samples);
         engine->sync();
-        engine->rebuild_master_canvas();
+        if (engine->render_errors) { cout << "Render failed: " << engine->last_error << endl; return 1; }
+        if (engine->rebuild_master_canvas() < 0) { cout << "Couldn't sum the films: " << engine->last_error << endl; return 1; }
 
         char output_path[4096];
         snprintf(output_path, sizeof output_path, "%s/frame%04i.png", vm["output-dir"].c_str(), frame);

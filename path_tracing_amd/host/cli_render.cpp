@@ -8,7 +8,11 @@
  * --resume FILE (stop a long render and continue it later from its accumulators).  --display
  * is accepted and ignored (there is no SDL preview).
  */
+#include <sys/time.h>
+#include <unistd.h>
+
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -21,6 +25,17 @@
 using namespace std;
 
 struct Option { const char* name; const char* def; const char* help; bool flag; };
+
+/* PT_CLI_TIMING=1: wall-clock seconds of each stage on stderr (where an end-to-end run spends its time). */
+static double wall_now() { struct timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + tv.tv_usec * 1e-6; }
+static double stage_t0 = 0;
+static void stage(const char* name) {
+    if (!getenv("PT_CLI_TIMING")) return;
+    double t = wall_now();
+    if (stage_t0 > 0) fprintf(stderr, "[timing] %-28s %.3f s\n", name, t - stage_t0);
+    else fprintf(stderr, "[timing] main() entered at %.3f\n", t);
+    stage_t0 = t;
+}
 
 static const Option OPTIONS[] = {
     {"help", nullptr, "Produce help message.", true},
@@ -103,7 +118,9 @@ int main(int argc, char** argv) {
 
     override_thread_count(atoi(vm["threads"].c_str()));
 
+    stage("start");
     auto scene = new Scene(path);
+    stage("scene (read, normals, tree)");
     if (scene->mesh == nullptr) return 1; /* the reference carries on with an unusable scene here */
     scene->lights->push_back(Light({Vec(0, 0, 3), 9.0 * Vec(0.8, 0.5, 0.25)}));
     scene->lights->push_back(Light({Vec(-2, 2, 4), 9.0 * Vec(0.25, 0.8, 0.25)}));
@@ -122,6 +139,7 @@ int main(int argc, char** argv) {
 
     auto engine = new RenderEngine(atoi(vm["width"].c_str()), atoi(vm["height"].c_str()), scene);
     if (engine->workers.empty()) { cout << "No GPU available." << endl; return 1; }
+    stage("engine (GPU init, upload)");
     engine->seed = strtoull(vm["seed"].c_str(), nullptr, 10);
     engine->tile_width = atoi(vm["tile-width"].c_str());
     engine->tile_height = atoi(vm["tile-height"].c_str());
@@ -147,15 +165,31 @@ int main(int argc, char** argv) {
     pr->main_loop();
     delete pr;
     engine->sync();
-    engine->rebuild_master_canvas();
+    stage("render");
+    if (engine->render_errors) { cout << "Render failed: " << engine->last_error << endl; return 1; }
+    if (engine->rebuild_master_canvas() < 0) { cout << "Couldn't sum the films: " << engine->last_error << endl; return 1; }
+    if (getenv("PT_FILMS_REDUCE")) cerr << "films summed by: " << engine->last_reduce_how << endl;
+    stage("rebuild_master_canvas");
     string output_path = vm["output"];
     if (engine->master_canvas->save(output_path) != 0) { cout << "Couldn't write: " << output_path << endl; return 1; }
     cout << "Wrote to: " << output_path << endl;
+    stage("save PNG");
     if (vm.count("checkpoint")) {
         if (engine->master_canvas->save_accumulators(vm["checkpoint"]) != 0) { cout << "Couldn't write: " << vm["checkpoint"] << endl; return 1; }
         cout << "Accumulators written to: " << vm["checkpoint"] << endl;
     }
-    delete engine;
-    delete scene;
-    return 0;
+    /* Like the reference (cli_render.cpp:127-128) the engine and the scene are not torn down piece
+     * by piece: the picture is on disk, and handing ~150 GB of render scratch back allocation by
+     * allocation costs 0.6 s that process exit does not.  PT_CLI_TEARDOWN=1 runs the destructors. */
+    if (getenv("PT_CLI_TEARDOWN")) {
+        delete engine;
+        delete scene;
+        stage("teardown");
+        return 0;
+    }
+    if (getenv("PT_CLI_TIMING")) fprintf(stderr, "[timing] leaving main() at %.3f\n", wall_now());
+    cout.flush();
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
 }

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 using namespace std;
 
@@ -73,18 +74,25 @@ static void fill_triangles(const pth_scene* built, vector<Triangle>& tris) {
     vector<float> data((size_t)n * 30);
     pth_triangle_data(built, data.data());
     tris.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        const float* d = &data[(size_t)i * 30];
-        Triangle& t = tris[(size_t)i];
-        for (int k = 0; k < 3; k++) t.points[k] = vec3(d + 3 * k);
-        t.edge01 = vec3(d + 9); t.edge02 = vec3(d + 12); t.normal = vec3(d + 15);
-        t.base_normal = vec3(d + 18); t.u_normal = vec3(d + 21); t.v_normal = vec3(d + 24);
-        for (int a = 0; a < 3; a++) {
-            t.aabb.minima(a) = real_min(real_min(t.points[0](a), t.points[1](a)), t.points[2](a));
-            t.aabb.maxima(a) = real_max(real_max(t.points[0](a), t.points[1](a)), t.points[2](a));
-        }
-        t.assigned_normal = t.normal;
-    }
+    /* 156 bytes per triangle to fill: a handful of threads, each its own slice */
+    const int n_threads = (int)max<int64_t>(1, min<int64_t>(8, n / 65536));
+    vector<thread> pool;
+    for (int w = 0; w < n_threads; w++)
+        pool.emplace_back([&, w]() {
+            for (int64_t i = n * w / n_threads; i < n * (w + 1) / n_threads; i++) {
+                const float* d = &data[(size_t)i * 30];
+                Triangle& t = tris[(size_t)i];
+                for (int k = 0; k < 3; k++) t.points[k] = vec3(d + 3 * k);
+                t.edge01 = vec3(d + 9); t.edge02 = vec3(d + 12); t.normal = vec3(d + 15);
+                t.base_normal = vec3(d + 18); t.u_normal = vec3(d + 21); t.v_normal = vec3(d + 24);
+                for (int a = 0; a < 3; a++) {
+                    t.aabb.minima(a) = real_min(real_min(t.points[0](a), t.points[1](a)), t.points[2](a));
+                    t.aabb.maxima(a) = real_max(real_max(t.points[0](a), t.points[1](a)), t.points[2](a));
+                }
+                t.assigned_normal = t.normal;
+            }
+        });
+    for (thread& th : pool) th.join();
 }
 
 void kdTreeNode::get_stats(int& deepest_depth, int& biggest_set) const {
@@ -118,6 +126,7 @@ kdTree::kdTree(vector<Triangle>* _all_triangles, pth_scene* prebuilt) : all_tria
 
 kdTree::~kdTree() {
     for (pt_scene* s : on_device) pt_scene_destroy(s);
+    for (pthread_mutex_t* m : device_mutex) if (m) { pthread_mutex_destroy(m); delete m; }
     if (built) pth_scene_destroy(built);
     delete root;
     pthread_mutex_destroy(&lock);
@@ -126,7 +135,8 @@ kdTree::~kdTree() {
 pt_scene* kdTree::device_scene(int device) {
     if (!built || device < 0) return nullptr;
     pthread_mutex_lock(&lock);
-    if ((int)on_device.size() <= device) on_device.resize((size_t)device + 1, nullptr);
+    if ((int)on_device.size() <= device) { on_device.resize((size_t)device + 1, nullptr); device_mutex.resize((size_t)device + 1, nullptr); }
+    if (!device_mutex[(size_t)device]) { device_mutex[(size_t)device] = new pthread_mutex_t; pthread_mutex_init(device_mutex[(size_t)device], NULL); }
     pt_scene* s = on_device[(size_t)device];
     if (!s) {
         if (pt_scene_create(device, pth_flat_scene(built), &s) != PT_OK) s = nullptr;
@@ -136,15 +146,28 @@ pt_scene* kdTree::device_scene(int device) {
     return s;
 }
 
+/* Held around every call that drives the device's pt_scene (the handles are not locked inside). */
+void kdTree::lock_device(int device) {
+    pthread_mutex_lock(&lock);
+    pthread_mutex_t* m = device >= 0 && device < (int)device_mutex.size() ? device_mutex[(size_t)device] : nullptr;
+    pthread_mutex_unlock(&lock);
+    if (m) pthread_mutex_lock(m);
+}
+void kdTree::unlock_device(int device) {
+    pthread_mutex_lock(&lock);
+    pthread_mutex_t* m = device >= 0 && device < (int)device_mutex.size() ? device_mutex[(size_t)device] : nullptr;
+    pthread_mutex_unlock(&lock);
+    if (m) pthread_mutex_unlock(m);
+}
+
 bool kdTree::ray_test(const Ray& ray, Real& hit_parameter, Real& hit_u, Real& hit_v, const Triangle** hit_triangle) {
     pt_scene* s = device_scene(0);
     if (!s) return false;
     int32_t idx = -1;
     float t = 0, u = 0, v = 0;
     float o[3] = {ray.origin(0), ray.origin(1), ray.origin(2)}, d[3] = {ray.direction(0), ray.direction(1), ray.direction(2)};
-    pthread_mutex_lock(&lock);
+    /* a cast of up to 64 rays is serialised inside the handle and independent of rendering */
     int rc = pt_raycast_closest(s, 1, &o[0], &o[1], &o[2], &d[0], &d[1], &d[2], &idx, &t, &u, &v);
-    pthread_mutex_unlock(&lock);
     __sync_fetch_and_add(&rays_cast, 1);
     if (rc != PT_OK || idx < 0) return false;
     hit_parameter = t; hit_u = u; hit_v = v;
@@ -163,7 +186,15 @@ Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integr
     lambertian_bounces = false;
     bounded_shadow_rays = false;
     mesh = nullptr; lights = nullptr; tree = nullptr;
+    /* the GPUs' contexts come up on a spare thread while this one reads the file and builds the tree */
+    pthread_t warm;
+    bool warming = pthread_create(&warm, nullptr, [](void*) -> void* {
+        int n = get_optimal_thread_count();
+        for (int i = 0; i < n; i++) (void)pt_device_prepare(i);
+        return nullptr;
+    }, nullptr) == 0;
     pth_scene* built = pth_scene_from_stl(path.c_str(), 0);
+    if (warming) pthread_join(warm, nullptr);
     if (built == nullptr) {
         cout << "Couldn't read input file." << endl;
         return;
@@ -275,7 +306,7 @@ int Canvas::save(string path) {
     uLongf clen = compressBound((uLong)raw.size());
     vector<unsigned char> comp(clen);
     int status = -1;
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) == Z_OK) {
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) == Z_OK) {
         static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
         fwrite(sig, 1, 8, fp);
         unsigned char ihdr[13] = {(unsigned char)(width >> 24), (unsigned char)(width >> 16), (unsigned char)(width >> 8), (unsigned char)width,
@@ -357,18 +388,23 @@ void Integrator::perform_pass(PassDescriptor desc) {
     fill_lights(lights, scene);
     pt_tile_pass p = {desc.start_x, desc.start_y, desc.width, desc.height, next_sample++, 1};
     pt_render_stats st;
-    if (pt_render_passes(film, &cam, lights.data(), (int)lights.size(), &p, 1, seed, &st) == PT_OK) {
-        __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
-        download();
-    }
+    scene->tree->lock_device(device);
+    int rc = pt_render_passes(film, &cam, lights.data(), (int)lights.size(), &p, 1, seed, &st);
+    scene->tree->unlock_device(device);
     last_pass_seconds = now_seconds() - t0;
+    if (rc != PT_OK) { cerr << "Integrator::perform_pass: " << pt_last_error() << endl; return; } /* a failed pass is not counted */
+    __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
+    download();
     passes++;
 }
 
 int Integrator::download() {
     if (!film) return -1;
     vector<float> rgb((size_t)canvas->size * 3);
-    if (pt_film_read(film, rgb.data(), canvas->per_pixel_passes) != PT_OK) return -1;
+    scene->tree->lock_device(device);
+    int rc = pt_film_read(film, rgb.data(), canvas->per_pixel_passes);
+    scene->tree->unlock_device(device);
+    if (rc != PT_OK) return -1;
     for (int i = 0; i < canvas->size; i++) canvas->pixels[i] = Vec(rgb[3 * (size_t)i], rgb[3 * (size_t)i + 1], rgb[3 * (size_t)i + 2]);
     return 0;
 }
@@ -394,45 +430,77 @@ void RenderThread::send_message(RenderMessage message) {
     sem_post(&parent->messages_semaphore);
 }
 
-void RenderThread::kill_immediately() { send_message(RenderMessage({true, PassDescriptor(), 0})); }
+void RenderThread::kill_immediately() { send_message(RenderMessage({true, PassDescriptor(), 0, 0})); }
+
+/* Paths (pixels x samples, rectangles padded to 8x8 blocks) one worker hands to one render call.
+ * 2^27 keeps a GPU at about 96 % of the rate of the largest batches while its scratch stays at
+ * 38 GB instead of 152 GB -- which a short render feels, because the driver clears that memory
+ * when the process ends (0.2 s against up to 1.3 s).  PT_ENGINE_BATCH_PATHS overrides it. */
+static size_t engine_batch_paths() {
+    const char* e = getenv("PT_ENGINE_BATCH_PATHS");
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 27;
+    return max<size_t>(v, 4096);
+}
 
 void* RenderThread::render_thread_main(void* cookie) {
     RenderThread* self = (RenderThread*)cookie;
     RenderEngine* eng = self->parent;
-    const size_t max_batch = 131072; /* tile passes per render call: 2^29 paths with 64x64 tiles */
+    const size_t max_paths = engine_batch_paths();
     vector<pt_tile_pass> batch;
     vector<pt_light> lights;
     while (true) {
         sem_wait(&eng->messages_semaphore);
         bool die = false;
-        size_t taken = 0; /* messages in this batch (an entry of `batch` may stand for several) */
+        size_t taken = 0;    /* passes in this batch */
+        size_t finished = 0; /* queue entries used up by this batch (each owes one post of passes_semaphore) */
+        size_t paths = 0;
         batch.clear();
         pthread_mutex_lock(&eng->messages_lock);
-        /* The message that woke us, then further ones already queued (each has a semaphore count
-         * of its own, consumed with sem_trywait): this worker's share of the queue, but at
-         * least about a thousand tile passes so that a batch keeps the GPU busy. */
-        size_t queued = eng->messages.size(), n_workers = max<size_t>(eng->workers.size(), 1);
-        size_t take = max((queued + n_workers - 1) / n_workers, min<size_t>(queued, 1024));
-        take = min(take, max_batch);
+        /* The entry that woke us, then further ones already queued (each has a semaphore count of
+         * its own, consumed with sem_trywait), until the batch holds this worker's share of the
+         * queued work or max_paths paths.  A run that does not fit is split: the rest stays at the
+         * head of the queue with its semaphore count. */
+        size_t queued_paths = 0;
+        for (const RenderMessage& m : eng->messages) {
+            if (m.do_die) continue;
+            PassDescriptor d = m.desc;
+            d.clamp_bounds(eng->width, eng->height);
+            queued_paths += (size_t)((d.width + 7) / 8) * (size_t)((d.height + 7) / 8) * 64 * m.count;
+            if (queued_paths > max_paths * eng->workers.size()) break;
+        }
+        const size_t share = min(max_paths, max<size_t>((queued_paths + eng->workers.size() - 1) / max<size_t>(eng->workers.size(), 1), (size_t)1 << 22));
         while (true) {
             if (eng->messages.empty()) break; /* queue was cleared by kill_workers */
-            RenderMessage m = eng->messages.front();
+            RenderMessage& m = eng->messages.front();
             if (m.do_die) {
                 if (batch.empty()) { eng->messages.pop_front(); die = true; }
                 else sem_post(&eng->messages_semaphore); /* leave it queued: render what we hold first */
                 break;
             }
-            eng->messages.pop_front();
-            taken++;
-            /* perform_full_passes queues all samples of a tile one after the other: a run of
-             * passes of one rectangle with consecutive sample numbers is ONE entry of the call */
+            PassDescriptor d = m.desc;
+            d.clamp_bounds(eng->width, eng->height);
+            const size_t per_pass = max<size_t>((size_t)((d.width + 7) / 8) * (size_t)((d.height + 7) / 8) * 64, 1);
+            size_t room = paths < share ? (share - paths) / per_pass : 0;
+            if (room == 0 && batch.empty()) room = 1; /* a single pass larger than the share still goes out (and may be refused below) */
+            if (room == 0) { sem_post(&eng->messages_semaphore); break; }
+            const uint32_t take = (uint32_t)min<size_t>(room, m.count);
+            /* a run that continues the previous entry (same rectangle, next sample) extends it */
             if (!batch.empty() && batch.back().x == m.desc.start_x && batch.back().y == m.desc.start_y &&
                 batch.back().w == m.desc.width && batch.back().h == m.desc.height &&
                 batch.back().first_sample + batch.back().n_samples == m.sample)
-                batch.back().n_samples++;
+                batch.back().n_samples += take;
             else
-                batch.push_back({m.desc.start_x, m.desc.start_y, m.desc.width, m.desc.height, m.sample, 1});
-            if (taken >= take || sem_trywait(&eng->messages_semaphore) != 0) break;
+                batch.push_back({m.desc.start_x, m.desc.start_y, m.desc.width, m.desc.height, m.sample, take});
+            taken += take;
+            paths += per_pass * take;
+            if (take < m.count) { /* split: the remainder keeps this entry and its wake-up */
+                m.sample += take; m.count -= take;
+                sem_post(&eng->messages_semaphore);
+                break;
+            }
+            eng->messages.pop_front();
+            finished++;
+            if (paths >= share || sem_trywait(&eng->messages_semaphore) != 0) break;
         }
         pthread_mutex_unlock(&eng->messages_lock);
         if (die) break;
@@ -449,19 +517,36 @@ void* RenderThread::render_thread_main(void* cookie) {
             fill_camera(cam, eng->scene); /* camera and lights are re-read for every batch */
             fill_lights(lights, eng->scene);
             pt_render_stats st;
+            eng->scene->tree->lock_device(in->device);
             int rc = pt_render_passes(in->film, &cam, lights.data(), (int)lights.size(), batch.data(), (int)batch.size(), eng->seed, &st);
-            if (rc == PT_OK) __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
-            else cerr << "render worker: " << pt_last_error() << endl;
+            eng->scene->tree->unlock_device(in->device);
+            if (rc == PT_OK) {
+                __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
+                in->passes += (int)taken;
+            } else {
+                /* the passes still count as completed below (sync() and the progress bar must end),
+                 * but the failure is on record and they are not in Integrator::passes */
+                string why = pt_last_error();
+                cerr << "render worker (GPU " << in->device << "): " << why << endl;
+                pthread_mutex_lock(&eng->master_lock);
+                eng->render_errors++;
+                eng->last_error = why;
+                pthread_mutex_unlock(&eng->master_lock);
+            }
+        } else {
+            pthread_mutex_lock(&eng->master_lock);
+            eng->render_errors++;
+            eng->last_error = "worker has no film on its GPU";
+            pthread_mutex_unlock(&eng->master_lock);
         }
         in->last_pass_seconds = now_seconds() - t0;
-        in->passes += (int)taken;
         pthread_mutex_unlock(&self->integrator_lock);
         self->is_running = false;
 
         pthread_mutex_lock(&eng->master_lock);
         eng->total_passes_completed += (int)taken;
         pthread_mutex_unlock(&eng->master_lock);
-        for (size_t i = 0; i < taken; i++) sem_post(&eng->passes_semaphore);
+        for (size_t i = 0; i < finished; i++) sem_post(&eng->passes_semaphore);
     }
     return nullptr;
 }
@@ -478,6 +563,9 @@ RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_widt
     total_passes_completed = 0;
     semaphore_passes_pending = 0;
     sample_base = 0;
+    render_errors = 0;
+    next_global_sample = 0;
+    mixed_rectangles = false;
     int n = get_optimal_thread_count();
     for (int i = 0; i < n; i++) workers.push_back(new RenderThread(this, i));
     if (workers.empty()) cerr << "RenderEngine: no GPU available (" << pt_last_error() << ")" << endl;
@@ -485,7 +573,7 @@ RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_widt
 
 RenderEngine::~RenderEngine() {
     sync();
-    for (auto worker : workers) worker->send_message(RenderMessage({true, PassDescriptor(), 0}));
+    for (auto worker : workers) worker->send_message(RenderMessage({true, PassDescriptor(), 0, 0}));
     for (auto worker : workers) pthread_join(worker->thread, nullptr);
     for (auto worker : workers) delete worker;
     sem_destroy(&passes_semaphore);
@@ -495,13 +583,43 @@ RenderEngine::~RenderEngine() {
     delete master_canvas;
 }
 
-void RenderEngine::issue_pass_desc(PassDescriptor desc) {
-    if (workers.empty()) return;
+void RenderEngine::issue_pass_desc(PassDescriptor desc) { issue_pass_run(desc, 1); }
+
+void RenderEngine::issue_pass_run(PassDescriptor desc, int count) {
+    if (workers.empty() || count <= 0) return;
     PassDescriptor key = desc;
     key.clamp_bounds(width, height);
-    uint32_t sample = sample_base + samples_issued[make_pair(make_pair(key.start_x, key.start_y), make_pair(key.width, key.height))]++;
-    int worker = (total_passes_issued++) % (int)workers.size();
-    workers[(size_t)worker]->send_message(RenderMessage({false, desc, sample}));
+    /* The random stream is keyed by (pixel, sample index), so a pixel must never see an index
+     * twice.  While every rectangle issued so far is either identical to or disjoint from every
+     * other (a fixed tiling, the normal case), each rectangle counts its own passes 0, 1, 2, ...:
+     * every pixel then gets consecutive indices.  The first rectangle that overlaps a different
+     * one switches the engine to ONE counter for all passes, started above every index handed
+     * out before. */
+    auto rect = make_pair(make_pair(key.start_x, key.start_y), make_pair(key.width, key.height));
+    auto found = samples_issued.find(rect);
+    if (found == samples_issued.end()) {
+        if (!mixed_rectangles)
+            for (const auto& kv : samples_issued) {
+                int ox = kv.first.first.first, oy = kv.first.first.second, ow = kv.first.second.first, oh = kv.first.second.second;
+                if (key.start_x < ox + ow && ox < key.start_x + key.width && key.start_y < oy + oh && oy < key.start_y + key.height) { mixed_rectangles = true; break; }
+            }
+        found = samples_issued.insert(make_pair(rect, 0u)).first;
+    }
+    uint32_t sample;
+    if (mixed_rectangles) {
+        for (const auto& kv : samples_issued) next_global_sample = max(next_global_sample, kv.second);
+        sample = sample_base + next_global_sample;
+        next_global_sample += (uint32_t)count;
+        found->second = next_global_sample;
+    } else {
+        sample = sample_base + found->second;
+        found->second += (uint32_t)count;
+    }
+    int worker = total_passes_issued % (int)workers.size();
+    pthread_mutex_lock(&master_lock);
+    total_passes_issued += count;
+    pthread_mutex_unlock(&master_lock);
+    workers[(size_t)worker]->send_message(RenderMessage({false, desc, sample, (uint32_t)count}));
     semaphore_passes_pending++;
 }
 
@@ -520,14 +638,16 @@ static bool tile_compare(const pair<int, int>& a, const pair<int, int>& b) {
 }
 
 void RenderEngine::perform_full_passes(int pass_count) { /* integrator.cpp:428-449: centre-out order */
+    /* The reference lists every tile pass_count times and sorts the list stably by distance from
+     * the centre, which leaves each tile's passes next to one another: the same order as sorting
+     * the tiles and issuing each one's passes as a run. */
     vector<pair<int, int>> tile_spots;
     for (int next_y = 0; next_y < height; next_y += tile_height)
-        for (int next_x = 0; next_x < width; next_x += tile_width)
-            for (int j = 0; j < pass_count; j++) tile_spots.push_back(pair<int, int>(next_x, next_y));
+        for (int next_x = 0; next_x < width; next_x += tile_width) tile_spots.push_back(pair<int, int>(next_x, next_y));
     global_tile_center_x = (width - tile_width) / 2.0;
     global_tile_center_y = (height - tile_height) / 2.0;
     stable_sort(tile_spots.begin(), tile_spots.end(), tile_compare);
-    for (auto spot : tile_spots) issue_pass_desc(PassDescriptor(spot.first, spot.second, tile_width, tile_height));
+    for (auto spot : tile_spots) issue_pass_run(PassDescriptor(spot.first, spot.second, tile_width, tile_height), pass_count);
 }
 
 void RenderEngine::sync() {
@@ -560,7 +680,9 @@ int RenderEngine::rebuild_master_canvas() {
      * workers' own canvases are then not refreshed.  PT_FILMS_REDUCE=host keeps the host-side
      * sum below, which is also the fallback if the collective cannot be set up. */
     const char* how = getenv("PT_FILMS_REDUCE");
-    const bool want_rccl = how ? strcmp(how, "rccl") == 0 : workers.size() > 1;
+    const bool forced_rccl = how && strcmp(how, "rccl") == 0;
+    const bool want_rccl = how ? forced_rccl : workers.size() > 1;
+    last_reduce_how = "host";
     if (want_rccl && !workers.empty()) {
         vector<pt_film*> films;
         for (auto worker : workers) {
@@ -568,18 +690,25 @@ int RenderEngine::rebuild_master_canvas() {
             if (worker->integrator->film) films.push_back(worker->integrator->film);
             total_passes += worker->integrator->passes;
         }
-        int rc = -1;
+        int rc = PT_ERR_DEVICE;
+        string why = "a worker has no film";
         if (films.size() == workers.size()) {
             vector<float> rgb((size_t)master_canvas->size * 3);
+            for (auto worker : workers) scene->tree->lock_device(worker->integrator->device);
             rc = pt_films_reduce(films.data(), (int)films.size(), rgb.data(), master_canvas->per_pixel_passes);
+            if (rc != PT_OK) why = pt_last_error();
+            for (auto worker : workers) scene->tree->unlock_device(worker->integrator->device);
             if (rc == PT_OK)
                 for (int i = 0; i < master_canvas->size; i++)
                     master_canvas->pixels[i] = Vec(rgb[3 * (size_t)i], rgb[3 * (size_t)i + 1], rgb[3 * (size_t)i + 2]);
         }
         for (auto worker : workers) pthread_mutex_unlock(&worker->integrator_lock);
-        if (rc == PT_OK) return total_passes;
-        cerr << "rebuild_master_canvas: device-side reduce failed (" << pt_last_error() << "), summing on the host" << endl;
+        if (rc == PT_OK) { last_reduce_how = "rccl"; return total_passes; }
+        last_error = "device-side film reduce failed: " + why;
+        cerr << "rebuild_master_canvas: " << last_error << (forced_rccl ? "" : "; summing on the host") << endl;
         master_canvas->zero();
+        if (forced_rccl) return -1; /* the collective was asked for by name: no silent substitute */
+        last_reduce_how = "host after rccl failed";
         total_passes = 0;
     }
     for (auto worker : workers) {
@@ -598,6 +727,8 @@ void RenderEngine::zero() {
     total_passes_completed = 0;
     samples_issued.clear(); /* a zeroed canvas starts its sample stream again: frames are reproducible */
     sample_base = 0;
+    next_global_sample = 0;
+    mixed_rectangles = false;
     for (auto worker : workers) {
         if (worker->integrator->film) pt_film_zero(worker->integrator->film);
         worker->integrator->canvas->zero();
@@ -633,7 +764,7 @@ bool ProgressBar::init() { return true; }
 
 void ProgressBar::main_loop() { /* visualizer.cpp:152-179 */
     int completed, issued;
-    double elapsed;
+    double elapsed, last_print = -1.0;
     do {
         struct timeval stop, result;
         gettimeofday(&stop, NULL);
@@ -643,16 +774,21 @@ void ProgressBar::main_loop() { /* visualizer.cpp:152-179 */
         completed = engine->total_passes_completed;
         pthread_mutex_unlock(&engine->master_lock);
         issued = engine->total_passes_issued;
-        double completion = issued ? completed / (double)issued : 1.0;
-        double total_time = elapsed / real_max(1e-4, completion);
-        double remaining = total_time - elapsed;
-        string str_elapsed = format_seconds_as_hms(elapsed, 7);
-        string str_remaining = format_seconds_as_hms(remaining, 7);
-        string str_total_time = format_seconds_as_hms(total_time, 7);
-        printf("\r[\033[93m%6.2f%%\033[0m] \033[94mElapsed:\033[0m %s   \033[94mRemaining:\033[0m %s   \033[94mTotal:\033[0m %s   \033[94mTile samples:\033[0m %i/%i",
-               100.0 * completion, str_elapsed.c_str(), str_remaining.c_str(), str_total_time.c_str(), completed, issued);
-        fflush(stdout);
-        if (completed < issued) usleep(engine->workers.empty() ? 0 : 50000);
+        /* the line is redrawn every 50 ms as in the reference, but completion is looked for every
+         * 2 ms: a render that takes a second should not wait 50 ms to be noticed */
+        if (elapsed - last_print >= 0.05 || completed >= issued || engine->workers.empty()) {
+            last_print = elapsed;
+            double completion = issued ? completed / (double)issued : 1.0;
+            double total_time = elapsed / real_max(1e-4, completion);
+            double remaining = total_time - elapsed;
+            string str_elapsed = format_seconds_as_hms(elapsed, 7);
+            string str_remaining = format_seconds_as_hms(remaining, 7);
+            string str_total_time = format_seconds_as_hms(total_time, 7);
+            printf("\r[\033[93m%6.2f%%\033[0m] \033[94mElapsed:\033[0m %s   \033[94mRemaining:\033[0m %s   \033[94mTotal:\033[0m %s   \033[94mTile samples:\033[0m %i/%i",
+                   100.0 * completion, str_elapsed.c_str(), str_remaining.c_str(), str_total_time.c_str(), completed, issued);
+            fflush(stdout);
+        }
+        if (completed < issued) usleep(engine->workers.empty() ? 0 : 2000);
         if (engine->workers.empty()) break;
     } while (completed < issued);
     double performance = rays_cast / real_max(1e-9, elapsed);

@@ -539,14 +539,16 @@ void pth_timings(const pth_scene* s, double out[3]) { out[0] = s->t_normals; out
 
 void pth_triangle_data(const pth_scene* s, float* out) {
     const Mesh& m = s->mesh;
-    for (int64_t i = 0; i < m.n; i++) {
-        F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
-        const F3 v[9] = {m.p0[i], m.p1[i], m.p2[i], e1, e2, m.normal[i], m.vn0[i], sub(m.vn1[i], m.vn0[i]), sub(m.vn2[i], m.vn0[i])};
-        float* o = out + 30 * i;
-        for (int k = 0; k < 9; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
-        o[27] = plane_of(m.normal[i], m.p0[i], m.p1[i], m.p2[i]);
-        o[28] = o[29] = 0.0f;
-    }
+    parallel_ranges(m.n, default_threads(), [&m, out](int64_t first, int64_t last) {
+        for (int64_t i = first; i < last; i++) {
+            F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
+            const F3 v[9] = {m.p0[i], m.p1[i], m.p2[i], e1, e2, m.normal[i], m.vn0[i], sub(m.vn1[i], m.vn0[i]), sub(m.vn2[i], m.vn0[i])};
+            float* o = out + 30 * i;
+            for (int k = 0; k < 9; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
+            o[27] = plane_of(m.normal[i], m.p0[i], m.p1[i], m.p2[i]);
+            o[28] = o[29] = 0.0f;
+        }
+    });
 }
 
 void pth_tree_stats(const pth_scene* s, int64_t stats[5]) {

@@ -94,7 +94,7 @@ def host_lib():
 
 
 HIP_SYMBOLS = [
-    "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_raycast_closest", "pt_raycast_closest_dev",
+    "pt_device_count", "pt_device_prepare", "pt_scene_create", "pt_scene_destroy", "pt_raycast_closest", "pt_raycast_closest_dev",
     "pt_raycast_closest_dev_noalloc",
     "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_raycast_occluded", "pt_raycast_occluded_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_film_create",
     "pt_film_destroy", "pt_film_zero", "pt_film_device_ptr", "pt_film_read", "pt_film_add", "pt_films_reduce", "pt_render_passes",
@@ -120,6 +120,7 @@ def hip_lib():
         L = C.CDLL(HIP_LIB)
         vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
         L.pt_device_count.argtypes = [C.POINTER(i32)]
+        L.pt_device_prepare.argtypes = [i32]
         L.pt_scene_create.argtypes = [i32, C.POINTER(FlatScene), C.POINTER(vp)]
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None

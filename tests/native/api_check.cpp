@@ -63,6 +63,40 @@ int main(int argc, char** argv) {
                    bits((*c)(2)), rgb[0], rgb[1], rgb[2]);
         }
     delete in;
+
+    /* RenderEngine with rectangles that overlap one another: a full-frame pass, four tiles, the
+     * full frame again, the first tile again.  No pixel may see a sample index twice: the engine
+     * numbers the passes 0; 1, 2, 3, 4; 5; 6.  Meanwhile this thread keeps casting single rays
+     * (the reference's ray_test may be called while workers render). */
+    RenderEngine* engine = new RenderEngine(W, H, scene);
+    engine->seed = 5;
+    engine->issue_pass_desc(PassDescriptor());
+    const int tw = W / 2, th = H / 2;
+    for (int k = 0; k < 4; k++) engine->issue_pass_desc(PassDescriptor((k & 1) * tw, (k >> 1) * th, tw, th));
+    engine->issue_pass_desc(PassDescriptor());
+    engine->issue_pass_desc(PassDescriptor(0, 0, tw, th));
+    Ray probe = Ray(scene->main_camera.origin, scene->main_camera.direction);
+    Real t0 = 0, u0 = 0, v0 = 0;
+    const Triangle* tri0 = nullptr;
+    bool hit0 = scene->tree->ray_test(probe, t0, u0, v0, &tri0);
+    int same = 0, casts = 0;
+    do {
+        Real t = 0, u = 0, v = 0;
+        const Triangle* tri = nullptr;
+        bool hit = scene->tree->ray_test(probe, t, u, v, &tri);
+        same += (hit == hit0 && tri == tri0 && bits(t) == bits(t0) && bits(u) == bits(u0) && bits(v) == bits(v0)) ? 1 : 0;
+        casts++;
+    } while (casts < 200);
+    engine->sync();
+    printf("concurrent %d %d %d\n", casts, same, hit0 ? 1 : 0);
+    int total = engine->rebuild_master_canvas();
+    printf("engine %d %d %d %s\n", total, engine->render_errors, engine->mixed_rectangles ? 1 : 0, engine->last_reduce_how.c_str());
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            Color* c = engine->master_canvas->pixel_ptr(x, y);
+            printf("epx %d %d %d %08x %08x %08x\n", x, y, *engine->master_canvas->per_pixel_passes_ptr(x, y), bits((*c)(0)), bits((*c)(1)), bits((*c)(2)));
+        }
+    delete engine;
     delete scene;
     return 0;
 }

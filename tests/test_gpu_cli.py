@@ -141,5 +141,6 @@ def test_device_side_film_reduce(tmp_path, scene_small):
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, PT_FILMS_REDUCE=how))
         assert res.returncode == 0, res.stdout + res.stderr
         assert "reduce failed" not in res.stderr, res.stderr
+        assert "films summed by: " + how in res.stderr, res.stderr       # the collective itself, not a fallback
         outs.append(_read_png(out))
     assert np.array_equal(outs[0], outs[1])
