@@ -292,12 +292,14 @@ PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
     const bool over_hi = hi_min_a < origin;  /* :310 */
     const bool over_lo = origin <= lo_max_a; /* :311 */
     const bool first_is_lo = !over_hi || over_lo;
-    const uint32_t first = first_is_lo ? n.lo_ref : n.hi_ref;
-    const uint32_t second = first_is_lo ? n.hi_ref : n.lo_ref;
-    /* and/or on the two outcomes instead of selects, so they stay wave masks */
-    const bool hit_first = (first_is_lo && hit_lo) || (!first_is_lo && hit_hi);
-    const bool hit_second = (first_is_lo && hit_hi) || (!first_is_lo && hit_lo);
-    if (hit_first && hit_second) {
+    /* Where the lane goes next: the child whose box is hit if there is only one, the first of the
+     * two if both are.  Written as selects under plain conditions so that these stay wave masks
+     * (a select between two outcomes would turn them into 0/1 registers). */
+    uint32_t next = hit_lo ? n.lo_ref : PT_REF_NONE;
+    next = hit_hi ? n.hi_ref : next;
+    next = (hit_lo && hit_hi && first_is_lo) ? n.lo_ref : next;
+    if (hit_lo && hit_hi) {
+        const uint32_t second = first_is_lo ? n.hi_ref : n.lo_ref;
         if (ANYHIT || (over_hi && over_lo)) {
             /* entered afterwards whatever the first child finds; any-hit stops at the first hit,
              * so there "afterwards" already means "the first child found nothing" */
@@ -312,7 +314,7 @@ PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
             L.local = inf;
         }
     }
-    lane_enter(L, hit_first ? first : (hit_second ? second : PT_REF_NONE));
+    lane_enter(L, next);
 }
 
 /* One triangle of the pending leaf, in stored order, strict '<' (:281-293). */

@@ -42,9 +42,9 @@ def main():
     line = json.loads(open(os.path.join(root, name)).read().strip().splitlines()[-1])
     steps_total = line["steps"] + line["warmup"]
     out = {"source": os.path.basename(root.rstrip("/")), "bench_line": {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}}
-    for name, kernel, key in (("closest", "k_trace<1>", "closest_rays"), ("shadow", "k_trace<2>", "shadow_rays")):
+    for name, kernel, count_key in (("closest", "k_trace<1>", "closest_rays"), ("shadow", "k_trace<2>", "shadow_rays")):
         # shadow rays: the traced ones (zero-weight light samples are counted but not traced)
-        rays = line.get(key + "_traced", line[key]) / line["steps"] * steps_total
+        rays = line.get(count_key + "_traced", line[count_key]) / line["steps"] * steps_total
         fetch_kb, nd = counter_sum(root, "FETCH_SIZE", kernel)
         write_kb, _ = counter_sum(root, "WRITE_SIZE", kernel)
         hit, _ = counter_sum(root, "TCC_HIT_sum", kernel)

@@ -15,3 +15,4 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   timeout -s KILL 120 rocprofv3 --pmc $grp -d $OUT/g$i -o pmc -- python3 scripts/raycast_bench.py --reps 2 "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed" >> $OUT/failed.txt
 done
 python3 scripts/rocpd_summary.py $OUT --kernels k_trace > $OUT/summary.txt
+[ "${KEEP_DB:-0}" = "1" ] || find $OUT -name "*.db" -delete

@@ -15,3 +15,4 @@ for grp in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" \
   timeout -s KILL 240 rocprofv3 --pmc $grp -d $OUT/g$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/g$i.log 2>&1 || echo "group $i ($grp) failed" >> $OUT/failed.txt
 done
 python3 scripts/rocpd_summary.py $OUT --kernels k_trace > $OUT/summary.txt
+[ "${KEEP_DB:-0}" = "1" ] || find $OUT -name "*.db" -delete

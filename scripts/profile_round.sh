@@ -5,7 +5,7 @@
 #      beyond --kernel-trace): HBM-side traffic (FETCH_SIZE, WRITE_SIZE), L2 hit rate, SQ busy/
 #      wait/VALU counters, L1 counters;
 #   3. text summaries via scripts/rocpd_summary.py and profiles/traffic.json for bench.py.
-# Usage: bash scripts/profile_round.sh <tag> ["extra bench.py flags"]
+# Usage: bash scripts/profile_round.sh <tag> ["extra bench.py flags" [traffic.json key]]
 set -u
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
@@ -27,4 +27,9 @@ done
 python3 scripts/rocpd_summary.py $OUT > $OUT/summary.txt
 grep -h '^{' $OUT/bench_stats.log > $OUT/bench_line_under_profiler.json
 grep -h '^{' $OUT/pmc1.log > $OUT/bench_line_under_pmc.json
+# traffic.json entry of this workload (third argument: its key, e.g. level10_3840x2160), merged into the tracked file's copy
+KEY=${3:-level8_1920x1080}
+python3 scripts/make_traffic_json.py $OUT $KEY profiles/traffic.json > $OUT/traffic.json
+# the databases are large (gpurun brings back at most 64 MiB): the summaries above are what is kept
+[ "${KEEP_DB:-0}" = "1" ] || find $OUT -name "*.db" -delete
 echo done > $OUT/finished.txt

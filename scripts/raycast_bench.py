@@ -105,6 +105,14 @@ def main():
                 np.array_equal(np.ascontiguousarray(g).view(np.uint32), np.ascontiguousarray(w).view(np.uint32))
                 for g, w in zip(got, (w_idx, w_t, w_u, w_v))))
             res["emulation_max_stack_dwords"] = int(worst)
+    if "lockstep" in sets:
+        # every ray 64 times in a row: a wave's lanes walk in lockstep, so each round runs ONE of the
+        # kernel's phases (node / triangle / pop) with all lanes -- what phase mixing costs otherwise
+        k = n // 64
+        sel = torch.arange(k, device=dev) * 64
+        rep = [p[sel].repeat_interleave(64).contiguous() for p in prim]
+        run_closest("primary_each_ray_x64", rep)
+        run_closest("primary_subset_once", [p[sel].contiguous() for p in prim])
     if "sphere" in sets:
         rng = np.random.default_rng(1234)
         m = args.sphere_rays

@@ -8,6 +8,9 @@
  *             section (each only if some lane needs it)
  *   policy 1  a round runs EITHER the triangle section (when at least tri_threshold lanes wait
  *             on a leaf, or no lane wants a node) OR the pop+node sections
+ *   policy 5  every lane holds TWO rays; each section of a round serves, per lane, one of its
+ *             rays that needs that section (a ray takes at most one step per round), so a
+ *             section finds work in more lanes (wave_sim_two)
  * Build: g++ -O2 -std=c++17 -ffp-contract=off -Iinclude -Ipath_tracing_amd/csrc -shared -fPIC
  */
 #include <cstdint>
@@ -44,6 +47,10 @@ struct CpuStack {
 }
 
 extern "C" {
+
+struct SimParams;
+struct SimStats;
+void wave_sim_two(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const SimParams* p, SimStats* out);
 
 struct SimParams {
     int policy, refill_min, tri_threshold, max_pops, tris_per_round, any_hit;
@@ -144,6 +151,88 @@ void wave_sim(const pt_flat_scene* sc, uint64_t n, const float* o, const float* 
                 ptc::ray_set_recip(L[i].r);
                 ptc::lane_start(L[i], sc->root_ref, root, scene_tame);
                 active[i] = !ptc::lane_finished(L[i]);
+            }
+        }
+    }
+    *out = s;
+}
+
+
+/* Two rays per lane.  Slot k of lane i is ray state L2[k][i].  tri_threshold is reused as the
+ * extra cost per section for choosing between a lane's two rays. */
+void wave_sim_two(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const SimParams* p, SimStats* out) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    ptc::RootBox root;
+    root.mnx = sc->root_min[0]; root.mny = sc->root_min[1]; root.mnz = sc->root_min[2];
+    root.mxx = sc->root_max[0]; root.mxy = sc->root_max[1]; root.mxz = sc->root_max[2];
+    const bool scene_tame = ptc::root_is_tame(root);
+    static ptc::Lane L[2][64];
+    static CpuStack st[2][64];
+    bool active[2][64];
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 64; i++) active[k][i] = false;
+    uint64_t next = 0;
+    SimStats s;
+    memset(&s, 0, sizeof s);
+    const bool any = p->any_hit != 0;
+    const double c_sel = p->tri_threshold;
+    while (true) {
+        int idle = 0;
+        for (int k = 0; k < 2; k++) for (int i = 0; i < 64; i++) idle += !active[k][i];
+        int start_slot[128], start_lane[128], n_start = 0;
+        if (idle && next < n && (idle >= p->refill_min || idle == 128)) {
+            for (int k = 0; k < 2; k++) for (int i = 0; i < 64 && next < n; i++) if (!active[k][i]) { start_slot[n_start] = k; start_lane[n_start++] = i; next++; }
+        }
+        if (next >= n && idle == 128 && n_start == 0) break;
+        s.rounds++;
+        s.cost += p->c_round;
+        bool did[2][64];
+        for (int k = 0; k < 2; k++) for (int i = 0; i < 64; i++) did[k][i] = false;
+        {   /* triangle section */
+            bool some = false;
+            for (int i = 0; i < 64; i++) for (int k = 0; k < 2; k++) if (active[k][i] && ptc::lane_has_leaf(L[k][i])) {
+                ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L[k][i]), tr);
+                if (any) ptc::lane_tri<true>(L[k][i], tr); else ptc::lane_tri<false>(L[k][i], tr);
+                s.lane_tri++; some = true; did[k][i] = true;
+                break;
+            }
+            if (some) { s.tri_sections++; s.cost += p->c_tri + c_sel; }
+        }
+        {   /* node section */
+            bool some = false;
+            for (int i = 0; i < 64; i++) for (int k = 0; k < 2; k++) {
+                ptc::Lane& l = L[k][i];
+                if (!active[k][i] || did[k][i] || !ptc::lane_has_node(l)) continue;
+                ptc::NodeData nd; mem.load_node(l.cur, nd);
+                if (any) { if (l.tame) ptc::lane_node<true, true>(l, nd, st[k][i]); else ptc::lane_node<true, false>(l, nd, st[k][i]); }
+                else { if (l.tame) ptc::lane_node<false, true>(l, nd, st[k][i]); else ptc::lane_node<false, false>(l, nd, st[k][i]); }
+                s.lane_node++; some = true; did[k][i] = true;
+                break;
+            }
+            if (some) { s.node_sections++; s.cost += p->c_node + c_sel; }
+        }
+        for (int r = 0; r < p->max_pops; r++) {   /* pop sections: one ray per lane each */
+            bool some = false;
+            for (int i = 0; i < 64; i++) for (int k = 0; k < 2; k++) {
+                ptc::Lane& l = L[k][i];
+                if (!active[k][i] || l.cur != PT_REF_NONE || l.sp <= 0) continue;
+                if (any) ptc::lane_pop<true>(l, st[k][i]); else ptc::lane_pop<false>(l, st[k][i]);
+                s.lane_pop++; some = true;
+                if (l.cur == PT_REF_NONE) s.lane_pop_culled++;
+                break;
+            }
+            if (some) { s.pop_sections++; s.cost += p->c_pop + c_sel; }
+        }
+        for (int k = 0; k < 2; k++) for (int i = 0; i < 64; i++) if (active[k][i] && ptc::lane_finished(L[k][i])) active[k][i] = false;
+        if (n_start) {
+            s.start_sections++; s.cost += p->c_start;
+            for (int q = 0; q < n_start; q++) {
+                int i = start_lane[q], k = start_slot[q];
+                uint64_t r = next - n_start + q;
+                L[k][i].r.ox = o[3 * r]; L[k][i].r.oy = o[3 * r + 1]; L[k][i].r.oz = o[3 * r + 2];
+                L[k][i].r.dx = d[3 * r]; L[k][i].r.dy = d[3 * r + 1]; L[k][i].r.dz = d[3 * r + 2];
+                ptc::ray_set_recip(L[k][i].r);
+                ptc::lane_start(L[k][i], sc->root_ref, root, scene_tame);
+                active[k][i] = !ptc::lane_finished(L[k][i]);
             }
         }
     }

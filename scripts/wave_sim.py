@@ -40,6 +40,7 @@ def main():
                            os.path.join(ROOT, "scripts", "wave_sim.cpp")])
     lib = C.CDLL(so)
     lib.wave_sim.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(SimParams), C.POINTER(SimStats)]
+    lib.wave_sim_two.argtypes = lib.wave_sim.argtypes
     import path_tracing_amd as pta
     import orc
     host = pta.HostScene(pta.meshgen.standin_scene(args.level), threads=8)
@@ -59,13 +60,19 @@ def main():
     policies = [("kernel: T|N then pops", dict(policy=4, max_pops=2, tris_per_round=1, tri_threshold=0))]
     for thr in (16, 32, 40, 48, 56):
         policies.append(("either thr=%d" % thr, dict(policy=1, max_pops=2, tris_per_round=1, tri_threshold=thr)))
+    for sel in (0, 10, 20):
+        for pops in (1, 2):
+            policies.append(("two rays/lane sel=%d pops=%d" % (sel, pops), dict(policy=5, max_pops=pops, tris_per_round=1, tri_threshold=sel)))
+    policies[0] = ("kernel: T|N then 1 pop", dict(policy=4, max_pops=1, tris_per_round=1, tri_threshold=0))
     for name, (oo, dd) in sets.items():
         n = len(oo)
         print("== %s: %d rays" % (name, n))
         for pname, kw in policies:
             p = SimParams(refill_min=8, any_hit=0, **kw, **costs)
             s = SimStats()
-            lib.wave_sim(C.byref(host.flat), n, oo.ctypes.data, dd.ctypes.data, C.byref(p), C.byref(s))
+            refill = 16 if kw["policy"] != 5 else 32
+            p.refill_min = refill
+            (lib.wave_sim_two if kw["policy"] == 5 else lib.wave_sim)(C.byref(host.flat), n, oo.ctypes.data, dd.ctypes.data, C.byref(p), C.byref(s))
             useful = s.lane_tri * p.c_tri + s.lane_pop * p.c_pop + s.lane_node * p.c_node
             print("  %-28s cost/ray %7.1f  rounds/ray*64 %6.1f  T/P/N sections per ray*64 %5.1f %5.1f %5.1f  "
                   "lane steps/ray T %.1f P %.1f (culled %.1f) N %.1f  util %.2f" % (
