@@ -56,8 +56,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 /* ------------------------------------------------------------ device views */
 
 struct DScene {
-    const float4* nodes;
-    const float4* tris;
+    const char* geom;     /* nodes, then (at byte tris_off) the triangle records: ONE allocation below 4 GiB, so that
+                             a lane's record address is this base plus a 32-bit offset */
+    uint32_t tris_off;
     const float4* shade;
     uint32_t root_ref;
     uint32_t n_tris;
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         rec_tri = active && lane_has_leaf(L);
         rec_node = active && lane_has_node(L);
         if (rec_tri || rec_node) {
-            const float4* rec = rec_tri ? sc.tris + (size_t)lane_leaf_pos(L) * 3 : sc.nodes + (size_t)L.cur * 4;
+            const uint32_t off = rec_tri ? sc.tris_off + lane_leaf_pos(L) * (uint32_t)sizeof(pt_tri_isect) : L.cur * (uint32_t)sizeof(pt_flat_node);
+            const float4* rec = (const float4*)(sc.geom + off);
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             if (rec_node) q3 = rec[3];
         }
@@ -887,8 +889,7 @@ struct pt_scene {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     DScene d{};
-    void* d_nodes = nullptr;
-    void* d_tris = nullptr;
+    void* d_geom = nullptr;  /* nodes and triangle records */
     void* d_shade = nullptr;
     uint64_t n_tris = 0;
     uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, two sets of queue heads at SMALL_HEADS0/1 */
@@ -1044,18 +1045,20 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     size_t nb = std::max<size_t>(flat->n_nodes, 1) * sizeof(pt_flat_node);
     size_t tb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_isect);
     size_t sb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_shade);
-    if (hipMalloc(&s->d_nodes, nb) != hipSuccess || hipMalloc(&s->d_tris, tb) != hipSuccess ||
+    const size_t tris_off = (nb + 255) & ~(size_t)255;
+    if (tris_off + tb >= ((size_t)1 << 32)) return cleanup(fail(PT_ERR_LIMIT, "nodes and triangle records exceed 4 GiB"));
+    if (hipMalloc(&s->d_geom, tris_off + tb) != hipSuccess ||
         hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, SMALL_WORDS * sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(PT_ERR_DEVICE, "hipMalloc failed for the scene arrays"));
     bool ok = true;
-    if (flat->n_nodes) ok = ok && hipMemcpy(s->d_nodes, flat->nodes, flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
+    if (flat->n_nodes) ok = ok && hipMemcpy(s->d_geom, flat->nodes, flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
     if (flat->n_tris) {
-        ok = ok && hipMemcpy(s->d_tris, flat->tris, flat->n_tris * sizeof(pt_tri_isect), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy((char*)s->d_geom + tris_off, flat->tris, flat->n_tris * sizeof(pt_tri_isect), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(s->d_shade, flat->shade, flat->n_tris * sizeof(pt_tri_shade), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) return cleanup(fail(PT_ERR_DEVICE, "hipMemcpy failed for the scene arrays"));
-    s->d.nodes = (const float4*)s->d_nodes;
-    s->d.tris = (const float4*)s->d_tris;
+    s->d.geom = (const char*)s->d_geom;
+    s->d.tris_off = (uint32_t)tris_off;
     s->d.shade = (const float4*)s->d_shade;
     s->d.root_ref = flat->root_ref;
     s->d.n_tris = (uint32_t)flat->n_tris;
@@ -1079,8 +1082,7 @@ void pt_scene_destroy(pt_scene* s) {
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     for (auto& t : s->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : s->free_events) (void)hipEventDestroy(e);
-    if (s->d_nodes) (void)hipFree(s->d_nodes);
-    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_geom) (void)hipFree(s->d_geom);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_small) (void)hipFree(s->d_small);
     if (s->d_spill) (void)hipFree(s->d_spill);
