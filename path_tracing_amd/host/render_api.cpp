@@ -567,7 +567,13 @@ RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_widt
     next_global_sample = 0;
     mixed_rectangles = false;
     int n = get_optimal_thread_count();
-    for (int i = 0; i < n; i++) workers.push_back(new RenderThread(this, i));
+    /* PT_ENGINE_WORKERS=k: k workers dealt to the GPUs in turn (more than one per GPU when k exceeds
+     * their number).  Renders no faster -- workers of one GPU take turns on it -- but runs the
+     * several-worker machinery (shared queue, split runs, one film per worker, their sum) on a
+     * machine with a single GPU. */
+    int k = n;
+    if (const char* e = getenv("PT_ENGINE_WORKERS")) { int v = atoi(e); if (v > 0 && n > 0) k = min(v, 64); }
+    for (int i = 0; i < k; i++) workers.push_back(new RenderThread(this, i % n));
     if (workers.empty()) cerr << "RenderEngine: no GPU available (" << pt_last_error() << ")" << endl;
 }
 
@@ -681,7 +687,11 @@ int RenderEngine::rebuild_master_canvas() {
      * sum below, which is also the fallback if the collective cannot be set up. */
     const char* how = getenv("PT_FILMS_REDUCE");
     const bool forced_rccl = how && strcmp(how, "rccl") == 0;
-    const bool want_rccl = how ? forced_rccl : workers.size() > 1;
+    bool one_film_per_gpu = true; /* the collective takes one film per GPU */
+    for (size_t a = 0; a < workers.size(); a++)
+        for (size_t b = 0; b < a; b++)
+            if (workers[a]->integrator->device == workers[b]->integrator->device) one_film_per_gpu = false;
+    const bool want_rccl = how ? forced_rccl : (workers.size() > 1 && one_film_per_gpu);
     last_reduce_how = "host";
     if (want_rccl && !workers.empty()) {
         vector<pt_film*> films;

@@ -144,3 +144,35 @@ def test_device_side_film_reduce(tmp_path, scene_small):
         assert "films summed by: " + how in res.stderr, res.stderr       # the collective itself, not a fallback
         outs.append(_read_png(out))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_two_workers_share_the_queue(tmp_path, scene_small):
+    """The several-worker machinery on a one-GPU box (PT_ENGINE_WORKERS=2: two workers, each with
+    its own film, both on GPU 0): runs of tile passes are split between the workers at batch
+    boundaries, every pass is rendered exactly once, and the summed films give the picture of one
+    worker (sums associate differently: at most one 8-bit level) and of the oracle."""
+    stl = str(tmp_path / "standin.stl")
+    pta.meshgen.write_stl(stl, scene_small.tris)
+    W, H, S = 320, 200, 24
+    outs = {}
+    for workers, batch in (("1", None), ("2", "65536"), ("3", "40000")):
+        out = str(tmp_path / ("w%s.png" % workers))
+        acc = str(tmp_path / ("w%s.acc" % workers))
+        env = dict(os.environ, PT_ENGINE_WORKERS=workers)
+        if batch:
+            env["PT_ENGINE_BATCH_PATHS"] = batch      # small batches: many hand-overs between the workers
+        cmd = [CLI, stl, "--output", out, "--width", str(W), "--height", str(H), "--samples", str(S), "--dof-aperture", "0.1",
+               "--dof-distance", "4.5", "--seed", "6", "--checkpoint", acc]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stdout + res.stderr
+        raw = open(acc, "rb").read()
+        passes = np.frombuffer(raw, "<i4", W * H, 16 + W * H * 12)
+        assert (passes == S).all(), (workers, passes.min(), passes.max())
+        outs[workers] = _read_png(out)
+    for workers in ("2", "3"):
+        diff = np.abs(outs["1"].astype(int) - outs[workers].astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (workers, diff.max(), (diff > 0).mean())
+    rgb, passes, _ = scene_small.oracle.render(orc.cli_camera(dof_aperture=0.1, dof_distance=4.5), orc.cli_lights(), W, H, None, 0, S, seed=6)
+    want = orc.tonemap(rgb, passes).reshape(H, W, 3)
+    diff = np.abs(outs["2"].astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
