@@ -18,7 +18,7 @@
  *   - rays_cast is maintained (the reference left its increment commented out,
  *     kdtree.cpp:578), so ProgressBar's "Perf: ...Mr/s" is a real number.
  *   - kdTree::ray_test hands back a pointer into Scene::mesh, not into a leaf's private copy.
- *   - Integrator::cast_ray and the SDL display (ProgressDisplay) are not provided.
+ *   - The SDL display (ProgressDisplay) is not provided.
  * Everything below the API goes through the C ABI of pt_hip.h; there is no CPU ray caster here.
  */
 #ifndef PT_RENDER_H
@@ -191,6 +191,17 @@ struct Integrator {
     Integrator(int width, int height, Scene* scene, int device = 0);
     ~Integrator();
     Ray get_ray_for_pixel(int x, int y);
+    /* Radiance along one ray of the caller's own (integrator.h:54, integrator.cpp:51-156), traced
+     * on this integrator's GPU as a one-path batch.  recursions 0..10.  The reference averages
+     * `branches` independent estimates of the bounce term at the first hit; here every call is
+     * one estimate whatever `branches` says (same expectation).  Each call draws from a stream
+     * of its own (seed, call number), so repeated calls give independent samples. */
+    Color cast_ray(const Ray& ray, int recursions, int branches);
+    /* integrator.h:50-51 has a public std::mt19937 `engine` that callers may re-seed
+     * (engine.seed(k)); this stands in for it: seeding it sets `seed` and restarts the
+     * call numbering of cast_ray. */
+    struct SeedHandle { Integrator* owner; void seed(uint64_t value); } engine;
+    uint32_t cast_calls;
     void perform_pass(PassDescriptor desc = PassDescriptor());
     int download(); /* film -> canvas */
 };

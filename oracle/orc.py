@@ -64,6 +64,7 @@ def lib():
         L.orc_camera_rays.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, u32, u64, vp, vp]
         L.orc_render.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, u32, u32, u64, vp, vp, vp, i32]
         L.orc_render_counting.argtypes = L.orc_render.argtypes
+        L.orc_cast_rays.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp, u32, i32, u64, vp, vp]
         L.orc_tonemap.argtypes = [vp, vp, i64, C.c_float, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_uniform01.restype = C.c_double
@@ -202,6 +203,19 @@ class Scene:
         fn(self.h, C.byref(cam), larr, len(lights), width, height, x0, y0, w, h, first_sample,
                          n_samples, seed, _p(rgb), _p(passes), _p(counts), threads)
         return rgb, passes, counts
+
+
+    def cast_rays(self, cam, lights, o, d, ids=None, sample=0, recursions=10, seed=1):
+        """Integrator::cast_ray for given rays: (rgb [n,3], [closest casts, shadow casts])."""
+        o = _f32(o).reshape(-1, 3)
+        d = _f32(d).reshape(-1, 3)
+        rgb = np.zeros((o.shape[0], 3), dtype=np.float32)
+        counts = np.zeros(2, dtype=np.uint64)
+        idarr = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        larr = make_lights(lights)
+        lib().orc_cast_rays(self.h, C.byref(cam), larr, len(lights), o.shape[0], _p(o), _p(d),
+                            _p(idarr) if idarr is not None else None, sample, recursions, seed, _p(rgb), _p(counts))
+        return rgb, counts
 
 
 def camera_rays(cam, width, height, rect=None, jittered=False, sample=0, seed=1):

@@ -983,6 +983,30 @@ void orc_render_counting(const orc_scene* s, const orc_camera* cam, const orc_li
                 work_counts, threads, true);
 }
 
+/* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for rays of the caller's own.
+ * Directions are used as given.  Ray i draws from the stream keyed by ids[i] (NULL: i) in place of
+ * a pixel number, and by `sample`.  counts = {closest casts, shadow casts}. */
+void orc_cast_rays(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int64_t n,
+                   const float* origins, const float* dirs, const uint32_t* ids, uint32_t sample, int recursions,
+                   uint64_t seed, float* rgb, uint64_t* counts) {
+    if (n_lights > MAX_LIGHTS) n_lights = MAX_LIGHTS;
+    PathCtx ctx;
+    ctx.scene = &s->s; ctx.lights = lights; ctx.n_lights = n_lights;
+    ctx.sky = mk(cam->sky_color[0], cam->sky_color[1], cam->sky_color[2]);
+    ctx.bounce_mode = cam->bounce_mode;
+    ctx.shadow_mode = cam->shadow_mode;
+    ctx.seed = seed; ctx.closest_casts = 0; ctx.shadow_casts = 0;
+    ctx.work_closest = nullptr; ctx.work_shadow = nullptr;
+    for (int64_t i = 0; i < n; i++) {
+        ctx.pixel = ids ? ids[i] : (uint32_t)i;
+        ctx.sample = sample;
+        Ray r = input_ray(origins, dirs, i, 0);
+        V3 c = cast_ray(ctx, r, recursions, 0);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+    }
+    if (counts) { counts[0] = ctx.closest_casts; counts[1] = ctx.shadow_casts; }
+}
+
 /* canvas.cpp:39-45 */
 void orc_tonemap(const float* rgb_sum, const int32_t* passes, int64_t n_pixels, float gain, uint8_t* rgb8) {
     for (int64_t i = 0; i < n_pixels; i++) {

@@ -113,6 +113,14 @@ void orc_render_counting(const orc_scene* s, const orc_camera* cam, const orc_li
                          uint32_t first_sample, uint32_t n_samples, uint64_t seed,
                          float* rgb_sum, int32_t* passes, uint64_t* work_counts, int threads);
 
+/* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for n given rays (origins and
+ * dirs are n*3 floats, directions used as given): rgb = n*3 floats.  ids (NULL: the ray's number)
+ * and sample key the random stream where a rendered path has its pixel and sample numbers.
+ * counts = {closest casts, shadow casts}. */
+void orc_cast_rays(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int64_t n,
+                   const float* origins, const float* dirs, const uint32_t* ids, uint32_t sample, int recursions,
+                   uint64_t seed, float* rgb, uint64_t* counts);
+
 /* Canvas::get_pixel for a whole image (canvas.cpp:39-45): rgb8 = W*H*3 bytes. */
 void orc_tonemap(const float* rgb_sum, const int32_t* passes, int64_t n_pixels, float gain,
                  uint8_t* rgb8);

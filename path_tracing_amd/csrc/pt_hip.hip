@@ -629,6 +629,17 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_generate(CamParams cam, const 
     }
 }
 
+/* Path state for rays supplied by the caller (pt_cast_rays): path p is ray p, its random stream
+ * is keyed by ids[p] (or p) in place of a pixel number. */
+__global__ __launch_bounds__(256) void k_seed_paths(uint32_t n, const uint32_t* ids, uint32_t sample, RenderBuffers b) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    b.pixel[p] = ids ? ids[p] : p;
+    b.sample[p] = sample;
+    b.rad_r[p] = 0.0f; b.rad_g[p] = 0.0f; b.rad_b[p] = 0.0f; b.thr[p] = 1.0f;
+    b.qpath[0][p] = p;
+}
+
 /* Camera rays only, row-major over a rectangle (parity checks of the generate step). */
 __global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int y0, int w, int h, int jittered,
                                                       uint32_t sample, uint64_t seed, RaySoAW out) {
@@ -1492,6 +1503,65 @@ static void fill_cam(CamParams& c, const pt_camera* cam, int width, int height) 
     c.shadow_mode = cam->shadow_mode;
 }
 
+/* The bounce loop of cast_ray (reference integrator.cpp:51-156) for the paths whose first rays sit
+ * in queue 0 (b.cnt[CNT_QUEUE] of them, counters otherwise zero): per depth the closest-hit trace,
+ * the shade kernel, the shadow traces, and after the last depth the light samples' sum.  Depth d
+ * is the reference's recursions = max_depth - d.  Everything is queued on ctx.stream with no host
+ * round trip. */
+static int enqueue_bounces(pt_scene* s, RenderBuffers& b, const LaunchCtx& ctx, const CamParams& cam, const DLight* d_lights,
+                           uint32_t n_lights, uint32_t max_depth, uint64_t seed) {
+    hipStream_t st = ctx.stream;
+    const int light_grid = s->num_cus * 8;
+    const int shade_grid = s->num_cus * SHADE_GRID_MUL;
+    /* PT_TRACE_ALL_SHADOW=1: trace the shadow rays of zero-weight light samples too (same picture; for checks) */
+    const char* all_env = getenv("PT_TRACE_ALL_SHADOW");
+    const int trace_all = (all_env && atoi(all_env) != 0) ? 1 : 0;
+    for (uint32_t depth = 0; depth <= max_depth; depth++) {
+        const int cur = depth & 1;
+        TraceArgs a{};
+        a.rays = {b.q[cur].ox, b.q[cur].oy, b.q[cur].oz, b.q[cur].dx, b.q[cur].dy, b.q[cur].dz};
+        a.d_count = b.cnt + CNT_QUEUE + depth;
+        a.d_next_chunk = b.cnt + CNT_CHUNK(0, depth);
+        a.out_hit = b.hit;
+        int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a, &ctx);
+        if (rc) return rc;
+        {
+            ScopedTimer tm(s, PT_KERNEL_SHADE, st);
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, st, s->d, cam, d_lights, n_lights, depth,
+                               depth == max_depth ? 1 : 0, trace_all, seed, b);
+            HIP_TRY(hipGetLastError());
+        }
+        if (n_lights > 0) {
+            TraceArgs sa{};
+            sa.rays = {b.sh.ox, b.sh.oy, b.sh.oz, b.sh.dx, b.sh.dy, b.sh.dz};
+            sa.d_count = b.cnt + CNT_SHADOW(depth); /* the light samples of this depth whose weight is not zero */
+            sa.count_mul = 1;
+            sa.target = b.sh_target;
+            sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
+            sa.dist = b.sh_dist; sa.vis = b.sh_vis[cur];
+            if (cam.shadow_mode == PT_SHADOW_BOUNDED) {
+                rc = launch_trace<TRACE_SHADOW_BOUNDED>(s, sa, &ctx);
+                if (rc) return rc;
+            } else {
+                sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
+                rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &ctx);
+                if (rc) return rc;
+                sa.d_count = b.cnt + CNT_DEFER + depth;
+                sa.count_mul = 1;
+                sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
+                rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
+                if (rc) return rc;
+            }
+            if (depth == max_depth) { /* the other depths' samples are added by the next depth's k_shade */
+                ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
+                hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, st, n_lights, depth, b);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+    return PT_OK;
+}
+
 /* Queues one batch (already clamped, grouped and numbered, in ln.h_sub) on the lane's stream
  * with no host round trip.  The film kernel waits for `after` (the previous batch's film
  * kernel, which may be on the other lane) so that batches reach the film in order; the batch's
@@ -1536,53 +1606,9 @@ static int render_batch(pt_film* f, RenderLane& ln, const LaunchCtx& ctx, const 
                            n_paths, seed, b);
         HIP_TRY(hipGetLastError());
     }
-    const int light_grid = s->num_cus * 8;
-    const int shade_grid = s->num_cus * SHADE_GRID_MUL;
-    /* PT_TRACE_ALL_SHADOW=1: trace the shadow rays of zero-weight light samples too (same picture; for checks) */
-    const char* all_env = getenv("PT_TRACE_ALL_SHADOW");
-    const int trace_all = (all_env && atoi(all_env) != 0) ? 1 : 0;
-    for (uint32_t depth = 0; depth <= 10; depth++) { /* cast_ray(ray, 10, 1): recursions 10..0 */
-        const int cur = depth & 1;
-        TraceArgs a{};
-        a.rays = {b.q[cur].ox, b.q[cur].oy, b.q[cur].oz, b.q[cur].dx, b.q[cur].dy, b.q[cur].dz};
-        a.d_count = b.cnt + CNT_QUEUE + depth;
-        a.d_next_chunk = b.cnt + CNT_CHUNK(0, depth);
-        a.out_hit = b.hit;
-        int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a, &ctx);
+    {
+        int rc = enqueue_bounces(s, b, ctx, cam, ln.d_lights, n_lights, 10, seed); /* cast_ray(ray, 10, 1): recursions 10..0 */
         if (rc) return rc;
-        {
-            ScopedTimer tm(s, PT_KERNEL_SHADE, st);
-            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, st, s->d, cam, ln.d_lights, n_lights, depth,
-                               depth == 10 ? 1 : 0, trace_all, seed, b);
-            HIP_TRY(hipGetLastError());
-        }
-        if (n_lights > 0) {
-            TraceArgs sa{};
-            sa.rays = {b.sh.ox, b.sh.oy, b.sh.oz, b.sh.dx, b.sh.dy, b.sh.dz};
-            sa.d_count = b.cnt + CNT_SHADOW(depth); /* the light samples of this depth whose weight is not zero */
-            sa.count_mul = 1;
-            sa.target = b.sh_target;
-            sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
-            sa.dist = b.sh_dist; sa.vis = b.sh_vis[cur];
-            if (cam.shadow_mode == PT_SHADOW_BOUNDED) {
-                rc = launch_trace<TRACE_SHADOW_BOUNDED>(s, sa, &ctx);
-                if (rc) return rc;
-            } else {
-                sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
-                rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &ctx);
-                if (rc) return rc;
-                sa.d_count = b.cnt + CNT_DEFER + depth;
-                sa.count_mul = 1;
-                sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
-                rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
-                if (rc) return rc;
-            }
-            if (depth == 10) { /* the other depths' samples are added by the next depth's k_shade */
-                ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);
-                hipLaunchKernelGGL(k_accumulate, dim3(light_grid), dim3(256), 0, st, n_lights, depth, b);
-                HIP_TRY(hipGetLastError());
-            }
-        }
     }
     if (after) HIP_TRY(hipStreamWaitEvent(st, after, 0));
     {
@@ -1935,6 +1961,67 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         stats->camera_samples = counts[0]; stats->closest_rays = counts[1]; stats->shadow_rays = counts[2];
         stats->shadow_rays_traced = counts[3];
         stats->gpu_ms = ms;
+    }
+    return PT_OK;
+}
+
+int pt_cast_rays(pt_scene* s, const pt_camera* cam, const pt_light* lights, int n_lights, uint64_t n, const float* ox,
+                 const float* oy, const float* oz, const float* dx, const float* dy, const float* dz, const uint32_t* stream_ids,
+                 uint32_t sample, int recursions, uint64_t seed, float* rgb, pt_render_stats* stats) {
+    if (!s || !cam || n_lights < 0 || (n_lights > 0 && !lights)) return fail(PT_ERR_INVALID, "bad argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n == 0) return PT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !rgb) return fail(PT_ERR_INVALID, "null array");
+    if (n_lights > PT_MAX_LIGHTS) return fail(PT_ERR_LIMIT, "more than PT_MAX_LIGHTS lights");
+    if (recursions < 0 || recursions > 10) return fail(PT_ERR_LIMIT, "recursions outside 0..10");
+    if (cam->bounce_mode > PT_BOUNCE_LAMBERT || cam->shadow_mode > PT_SHADOW_BOUNDED) return fail(PT_ERR_INVALID, "unknown bounce_mode or shadow_mode");
+    if (n * (uint64_t)std::max(n_lights, 1) > PT_MAX_RAYS_PER_CALL || n > ((uint64_t)1 << 28)) return fail(PT_ERR_LIMIT, "too many rays in one pt_cast_rays call");
+    int rc = set_device(s);
+    if (rc) return rc;
+    /* scratch that lives for the call */
+    struct Scratch { RenderLane ln; uint32_t* d_ids = nullptr; ~Scratch() { lane_free_scratch(&ln); if (ln.h_cnt) (void)hipHostFree(ln.h_cnt); if (ln.film_done) (void)hipEventDestroy(ln.film_done); if (d_ids) (void)hipFree(d_ids); } } sc;
+    rc = lane_ensure_scratch(&sc.ln, (size_t)n, (uint32_t)n_lights, 1);
+    if (rc) return rc;
+    RenderBuffers& b = sc.ln.rb;
+    hipStream_t st = s->stream;
+    CamParams cp;
+    fill_cam(cp, cam, 1, 1);   /* only sky colour and the two modes are used past the camera rays */
+    DLight hl[PT_MAX_LIGHTS];
+    for (int l = 0; l < n_lights; l++) {
+        hl[l].pos = v3(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
+        hl[l].color = v3(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
+    }
+    if (n_lights > 0) HIP_TRY(hipMemcpyAsync(sc.ln.d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, st));
+    const uint32_t n32 = (uint32_t)n;
+    HIP_TRY(hipMemcpyAsync(b.cnt + CNT_QUEUE, &n32, 4, hipMemcpyHostToDevice, st));
+    const float* src[6] = {ox, oy, oz, dx, dy, dz};
+    float* dst[6] = {b.q[0].ox, b.q[0].oy, b.q[0].oz, b.q[0].dx, b.q[0].dy, b.q[0].dz};
+    for (int k = 0; k < 6; k++) HIP_TRY(hipMemcpyAsync(dst[k], src[k], n * 4, hipMemcpyHostToDevice, st));
+    if (stream_ids) {
+        HIP_TRY(hipMalloc((void**)&sc.d_ids, n * 4));
+        HIP_TRY(hipMemcpyAsync(sc.d_ids, stream_ids, n * 4, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_seed_paths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n32, sc.d_ids, sample, b);
+    HIP_TRY(hipGetLastError());
+    const LaunchCtx ctx{st, s->d_spill};
+    rc = enqueue_bounces(s, b, ctx, cp, sc.ln.d_lights, (uint32_t)n_lights, (uint32_t)recursions, seed);
+    if (rc) return rc;
+    std::vector<float> r((size_t)n), g((size_t)n), bl((size_t)n);
+    HIP_TRY(hipMemcpyAsync(r.data(), b.rad_r, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(g.data(), b.rad_g, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(bl.data(), b.rad_b, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sc.ln.h_cnt, b.cnt, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n; i++) { rgb[3 * i] = r[(size_t)i]; rgb[3 * i + 1] = g[(size_t)i]; rgb[3 * i + 2] = bl[(size_t)i]; }
+    if (stats) {
+        const uint32_t* h = sc.ln.h_cnt;
+        stats->camera_samples = n;
+        for (int d = 0; d <= recursions; d++) {
+            stats->closest_rays += h[CNT_QUEUE + d];
+            stats->shadow_rays += (uint64_t)h[CNT_QUEUE + d + 1] * (uint64_t)n_lights;
+            if (n_lights) stats->shadow_rays_traced += h[CNT_SHADOW(d)];
+        }
     }
     return PT_OK;
 }

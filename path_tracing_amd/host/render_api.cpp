@@ -352,7 +352,8 @@ static double now_seconds() {
 }
 
 Integrator::Integrator(int width, int height, Scene* _scene, int _device)
-    : scene(_scene), passes(0), last_pass_seconds(0), seed(1), device(_device), film(nullptr), next_sample(0) {
+    : scene(_scene), passes(0), last_pass_seconds(0), seed(1), device(_device), film(nullptr), next_sample(0), cast_calls(0) {
+    engine.owner = this;
     canvas = new Canvas(width, height);
     canvas->zero();
     pt_scene* ds = scene && scene->tree ? scene->tree->device_scene(device) : nullptr;
@@ -375,6 +376,30 @@ Ray Integrator::get_ray_for_pixel(int x, int y) { /* integrator.cpp:197-209 */
     Real dy = -scene->camera_image_plane_width * (y - canvas->height / 2) * aspect_ratio / (Real)canvas->height;
     Vec offset = camera_right * dx + camera_up * dy;
     return Ray(scene->main_camera.origin, scene->main_camera.direction + offset);
+}
+
+void Integrator::SeedHandle::seed(uint64_t value) { owner->seed = value; owner->cast_calls = 0; }
+
+Color Integrator::cast_ray(const Ray& ray, int recursions, int branches) {
+    (void)branches;
+    pt_scene* ds = scene && scene->tree ? scene->tree->device_scene(device) : nullptr;
+    if (!ds) return Color(0, 0, 0);
+    pt_camera cam;
+    fill_camera(cam, scene);
+    vector<pt_light> lights;
+    fill_lights(lights, scene);
+    float o[3] = {ray.origin(0), ray.origin(1), ray.origin(2)}, d[3] = {ray.direction(0), ray.direction(1), ray.direction(2)};
+    /* streams of caller-made rays are kept apart from those of pixels (which are below 2^31) */
+    uint32_t id = 0x80000000u | (cast_calls++ & 0x7fffffffu);
+    float rgb[3] = {0, 0, 0};
+    pt_render_stats st;
+    scene->tree->lock_device(device);
+    int rc = pt_cast_rays(ds, &cam, lights.data(), (int)lights.size(), 1, &o[0], &o[1], &o[2], &d[0], &d[1], &d[2], &id, 0,
+                          min(max(recursions, 0), 10), seed, rgb, &st);
+    scene->tree->unlock_device(device);
+    if (rc != PT_OK) { cerr << "Integrator::cast_ray: " << pt_last_error() << endl; return Color(0, 0, 0); }
+    __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));
+    return Color(rgb[0], rgb[1], rgb[2]);
 }
 
 /* One pass over the rectangle on this integrator's GPU, then the film is copied back so that

@@ -98,7 +98,7 @@ HIP_SYMBOLS = [
     "pt_raycast_closest_dev_noalloc",
     "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_raycast_occluded", "pt_raycast_occluded_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_film_create",
     "pt_film_destroy", "pt_film_zero", "pt_film_device_ptr", "pt_film_read", "pt_film_add", "pt_films_reduce", "pt_render_passes",
-    "pt_camera_rays_dev", "pt_last_error", "pt_build_info",
+    "pt_camera_rays_dev", "pt_cast_rays", "pt_last_error", "pt_build_info",
 ]
 
 
@@ -144,6 +144,7 @@ def hip_lib():
         L.pt_films_reduce.argtypes = [vp, i32, vp, vp]
         L.pt_render_passes.argtypes = [vp, C.POINTER(Camera), vp, i32, vp, i32, u64, C.POINTER(RenderStats)]
         L.pt_camera_rays_dev.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, u32, u64] + [vp] * 6
+        L.pt_cast_rays.argtypes = [vp, C.POINTER(Camera), vp, i32, u64] + [vp] * 7 + [u32, i32, u64, vp, C.POINTER(RenderStats)]
         L.pt_last_error.restype = C.c_char_p
         L.pt_build_info.restype = C.c_char_p
         _hip = L

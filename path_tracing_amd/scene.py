@@ -217,6 +217,21 @@ class GpuScene:
         check(getattr(native.hip_lib(), name)(
             self.h, n, *ptrs, C.c_void_p(dist.data_ptr()), C.c_void_p(out_vis.data_ptr())), name)
 
+    def cast_rays(self, cam: Camera, lights, origins, dirs, stream_ids=None, sample=0, recursions=10, seed=1):
+        """Radiance along each given ray (Integrator::cast_ray); returns (rgb [n,3], RenderStats)."""
+        o = _f32(origins).reshape(-1, 3)
+        d = _f32(dirs).reshape(-1, 3)
+        n = o.shape[0]
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.uint32)
+        rgb = np.zeros((n, 3), dtype=np.float32)
+        st = RenderStats()
+        larr = make_lights(lights)
+        check(native.hip_lib().pt_cast_rays(self.h, C.byref(cam), larr, len(lights), n, *[_p(c) for c in cols],
+                                            _p(ids) if ids is not None else None, sample, recursions, seed, _p(rgb), C.byref(st)),
+              "pt_cast_rays")
+        return rgb, st
+
     def camera_rays_dev(self, cam: Camera, width, height, rect, jittered, sample, seed, out6):
         x, y, w, h = rect
         ptrs = [C.c_void_p(t.data_ptr()) for t in out6]

@@ -49,6 +49,15 @@ int main(int argc, char** argv) {
                    bits(r.origin(2)), bits(r.direction(0)), bits(r.direction(1)), bits(r.direction(2)), idx, bits(hit ? t : 0.0f),
                    bits(hit ? u : 0.0f), bits(hit ? v : 0.0f));
         }
+    /* Integrator::cast_ray on a few pixel-centre rays, re-seeded as the reference's engine can be */
+    in->engine.seed(9);
+    for (int k = 0; k < 6; k++) {
+        Ray r = in->get_ray_for_pixel(5 + 9 * k, 4 + 7 * k);
+        Color c = in->cast_ray(r, k == 5 ? 2 : 10, 1);
+        printf("cast %d %08x %08x %08x %08x %08x %08x rgb %08x %08x %08x\n", k, bits(r.origin(0)), bits(r.origin(1)), bits(r.origin(2)),
+               bits(r.direction(0)), bits(r.direction(1)), bits(r.direction(2)), bits(c(0)), bits(c(1)), bits(c(2)));
+    }
+    in->seed = 5;
     /* two passes over a rectangle, one over the whole frame */
     in->perform_pass(PassDescriptor(8, 4, 24, 16));
     in->perform_pass(PassDescriptor(8, 4, 24, 16));

@@ -50,6 +50,19 @@ def test_cpp_api_against_oracle(tmp_path, scene_small):
         assert np.array_equal(bits(np.ascontiguousarray(got_tuv[:, k])), bits(want[k + 1]))
     assert (got_idx >= 0).any() and (got_idx < 0).any()
 
+    # Integrator::cast_ray: one-path batches, stream (seed 9, call number | 2^31)
+    casts = [l.split() for l in lines if l.startswith("cast ")]
+    assert len(casts) == 6
+    for c in casts:
+        k = int(c[1])
+        o1 = np.array([[_f(w) for w in c[2:5]]], np.float32)
+        d1 = np.array([[_f(w) for w in c[5:8]]], np.float32)
+        got = np.array([_f(w) for w in c[9:12]], np.float32)
+        want, _ = scene_small.oracle.cast_rays(cam, orc.cli_lights(), o1, d1, ids=[0x80000000 | k], sample=0,
+                                               recursions=2 if k == 5 else 10, seed=9)
+        assert (np.abs(got - want[0]) <= 1e-5 * np.maximum(np.abs(want[0]), 1.0)).all(), (k, got, want)
+    assert any(float(_f(c[9])) > 0 for c in casts)
+
     # passes: Integrator numbers its passes 0, 1, 2 whatever their rectangle
     assert [l for l in lines if l.startswith("passes ")][0] == "passes 3"
     rgb = np.zeros((H, W, 3), np.float32)

@@ -3,7 +3,7 @@ Bar: bit-exact triangle index, t, u, v (integer/bit equality, no tolerance)."""
 import numpy as np
 import pytest
 
-from conftest import all_ray_sets, assert_hits_equal, orc, pta
+from conftest import all_ray_sets, assert_hits_equal, orc, pta, rays_sphere
 
 pytestmark = pytest.mark.gpu
 
@@ -247,3 +247,30 @@ def test_zero_weight_shadow_rays_are_counted_not_traced(scene_small, monkeypatch
     assert (st.closest_rays, st.shadow_rays) == (st_all.closest_rays, st_all.shadow_rays)
     assert st_all.shadow_rays_traced == st_all.shadow_rays
     assert 0 < st.shadow_rays_traced < st.shadow_rays
+
+
+def test_cast_rays_matches_oracle(scene_medium):
+    """pt_cast_rays = Integrator::cast_ray for the caller's own rays: radiance per ray against the
+    oracle's recursion for full depth, three bounces and none, sky and both extensions included."""
+    sc = scene_medium
+    cam_o = orc.cli_camera()
+    o, d = orc.camera_rays(cam_o, 96, 64)
+    so, sd = rays_sphere(4000, seed=31)
+    o = np.concatenate([o, so]); d = np.concatenate([d, sd])
+    ids = (np.arange(len(o), dtype=np.uint32) * np.uint32(2654435761)) | np.uint32(0x80000000)
+    for rec, sky, bounce, shadow in ((10, (0, 0, 0), 0, 0), (3, (0.2, 0.3, 0.4), 0, 0), (0, (0, 0, 0), 0, 0), (10, (0.1, 0.1, 0.1), 1, 1)):
+        co = orc.cli_camera(bounce_mode=bounce, shadow_mode=shadow)
+        cg = pta.cli_camera(bounce_mode=bounce, shadow_mode=shadow)
+        co.sky_color[:] = list(sky)
+        cg.sky_color[:] = list(sky)
+        want, counts = sc.oracle.cast_rays(co, orc.cli_lights(), o, d, ids=ids, sample=7, recursions=rec, seed=12)
+        got, st = sc.gpu.cast_rays(cg, pta.cli_lights(), o, d, stream_ids=ids, sample=7, recursions=rec, seed=12)
+        assert (st.closest_rays, st.shadow_rays) == (int(counts[0]), int(counts[1])), rec
+        assert (np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1.0)).all(), (rec, np.abs(got - want).max())
+        assert got.sum() > 0
+    # without ids the ray's number keys the stream
+    want, _ = sc.oracle.cast_rays(cam_o, orc.cli_lights(), o[:500], d[:500], sample=1, recursions=10, seed=3)
+    got, _ = sc.gpu.cast_rays(pta.cli_camera(), pta.cli_lights(), o[:500], d[:500], sample=1, recursions=10, seed=3)
+    assert (np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1.0)).all()
+    with pytest.raises(Exception):
+        sc.gpu.cast_rays(pta.cli_camera(), pta.cli_lights(), o[:4], d[:4], recursions=11)
