@@ -211,3 +211,26 @@ def test_vertex_normals_sorted_formulation_equals_the_map(scene_medium, monkeypa
     assert np.array_equal(bits(fast), bits(slow))
     monkeypatch.delenv("ORC_VERTEX_NORMALS")
     assert np.array_equal(bits(orc.Scene(tris, threads=1).triangle_data()), bits(fast))
+
+
+def test_plumbing_configuration_on_the_cpu(tmp_path, scene_small):
+    """The smallest benchmark configuration, end to end without a GPU: a ~1 k-triangle STL from
+    disk, 320x240, 16 samples per pixel, default cli_render camera and lights, written as a PNG.
+    Every one of the 76 800 pixels must have received exactly 16 passes, and loading the scene from
+    the file must give what the in-memory triangles give."""
+    from PIL import Image
+    stl = str(tmp_path / "standin.stl")
+    pta.meshgen.write_stl(stl, scene_small.tris)
+    scene = orc.Scene(stl_path=stl, threads=4)
+    assert scene.n == scene_small.oracle.n and scene.tree_hash() == scene_small.oracle.tree_hash()
+    W, H, S = 320, 240, 16
+    rgb, passes, counts = scene.render(orc.cli_camera(), orc.cli_lights(), W, H, None, 0, S, seed=1, threads=8)
+    assert passes.shape == (H, W) and (passes == S).all() and passes.size == 76800
+    assert int(counts[0]) >= W * H * S and int(counts[1]) % 3 == 0
+    img = orc.tonemap(rgb, passes).reshape(H, W, 3)
+    out = str(tmp_path / "out.png")
+    Image.fromarray(img, "RGB").save(out)
+    back = np.asarray(Image.open(out))
+    assert np.array_equal(back, img) and img.max() > 64 and (img.sum(axis=2) == 0).mean() < 0.9
+    again, _, _ = scene_small.oracle.render(orc.cli_camera(), orc.cli_lights(), W, H, None, 0, S, seed=1, threads=3)
+    assert np.array_equal(bits(again), bits(rgb))
