@@ -236,8 +236,9 @@ struct RenderEngine { /* integrator.h:91-127 */
     uint64_t seed;
 
     std::vector<RenderThread*> workers;
-    sem_t passes_semaphore;
+    sem_t passes_semaphore;          /* posted once per finished queue entry (reference field; sync() does not wait on it) */
     int semaphore_passes_pending;
+    pthread_cond_t passes_cond;      /* signalled under master_lock whenever total_passes_completed grows */
     sem_t messages_semaphore;
     pthread_mutex_t messages_lock;
     std::list<RenderMessage> messages;

@@ -570,6 +570,7 @@ void* RenderThread::render_thread_main(void* cookie) {
 
         pthread_mutex_lock(&eng->master_lock);
         eng->total_passes_completed += (int)taken;
+        pthread_cond_broadcast(&eng->passes_cond);
         pthread_mutex_unlock(&eng->master_lock);
         for (size_t i = 0; i < finished; i++) sem_post(&eng->passes_semaphore);
     }
@@ -578,6 +579,7 @@ void* RenderThread::render_thread_main(void* cookie) {
 
 RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_width), height(_height), scene(_scene), seed(1) {
     sem_init(&passes_semaphore, 0, 0);
+    pthread_cond_init(&passes_cond, NULL);
     pthread_mutex_init(&master_lock, NULL);
     sem_init(&messages_semaphore, 0, 0);
     pthread_mutex_init(&messages_lock, NULL);
@@ -608,6 +610,7 @@ RenderEngine::~RenderEngine() {
     for (auto worker : workers) pthread_join(worker->thread, nullptr);
     for (auto worker : workers) delete worker;
     sem_destroy(&passes_semaphore);
+    pthread_cond_destroy(&passes_cond);
     pthread_mutex_destroy(&master_lock);
     sem_destroy(&messages_semaphore);
     pthread_mutex_destroy(&messages_lock);
@@ -681,19 +684,29 @@ void RenderEngine::perform_full_passes(int pass_count) { /* integrator.cpp:428-4
     for (auto spot : tile_spots) issue_pass_run(PassDescriptor(spot.first, spot.second, tile_width, tile_height), pass_count);
 }
 
+/* Waits until every pass issued so far has been rendered.  Completion is counted in passes, under
+ * master_lock: a run of passes may be rendered in parts by several workers, so "its last part has
+ * been taken" would not mean "all of it is done". */
 void RenderEngine::sync() {
-    while (semaphore_passes_pending) {
-        semaphore_passes_pending--;
-        sem_wait(&passes_semaphore);
-    }
+    pthread_mutex_lock(&master_lock);
+    while (total_passes_completed < total_passes_issued && !workers.empty()) pthread_cond_wait(&passes_cond, &master_lock);
+    pthread_mutex_unlock(&master_lock);
+    while (sem_trywait(&passes_semaphore) == 0) {} /* kept for callers that look at it; nothing waits on it */
+    semaphore_passes_pending = 0;
 }
 
 /* Drops every pass that has not started yet and stops the workers; passes already on a GPU
  * finish first.  No more passes may be issued afterwards. */
 void RenderEngine::kill_workers() {
     pthread_mutex_lock(&messages_lock);
+    int dropped = 0;
+    for (const RenderMessage& m : messages) if (!m.do_die) dropped += (int)m.count;
     messages.clear();
     pthread_mutex_unlock(&messages_lock);
+    pthread_mutex_lock(&master_lock);
+    total_passes_issued -= dropped; /* they will never complete */
+    pthread_cond_broadcast(&passes_cond);
+    pthread_mutex_unlock(&master_lock);
     for (auto worker : workers) worker->kill_immediately();
     for (auto worker : workers) pthread_join(worker->thread, nullptr);
     for (auto worker : workers) delete worker;
