@@ -269,6 +269,7 @@ struct RenderEngine { /* integrator.h:91-127 */
     std::string last_error;
     std::string last_reduce_how;
     uint32_t next_global_sample; /* see issue_pass_desc */
+    bool hold_queue;             /* perform_full_passes holds messages_lock while it queues its runs */
     bool mixed_rectangles;
     /* Continues a render: zero(), then the canvas' accumulators become the first worker's film
      * and every rectangle's sample stream starts after the samples the canvas already holds

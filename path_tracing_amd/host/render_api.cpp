@@ -200,10 +200,18 @@ Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integr
         return;
     }
     mesh = new vector<Triangle>();
-    fill_triangles(built, *mesh);
-    cout << "Read in " << mesh->size() << " triangles." << endl;
-    /* adopt the already built tree instead of building it a second time from the points */
+    /* adopt the already built tree instead of building it a second time from the points; its flat
+     * arrays go up to the GPUs on a spare thread while this one fills in the host-side mesh */
     tree = new kdTree(mesh, built);
+    pthread_t upload;
+    bool uploading = pthread_create(&upload, nullptr, [](void* t) -> void* {
+        int n = get_optimal_thread_count();
+        for (int i = 0; i < n; i++) (void)((kdTree*)t)->device_scene(i);
+        return nullptr;
+    }, tree) == 0;
+    fill_triangles(built, *mesh);
+    if (uploading) pthread_join(upload, nullptr);
+    cout << "Read in " << mesh->size() << " triangles." << endl;
     lights = new vector<Light>();
 }
 
@@ -306,7 +314,7 @@ int Canvas::save(string path) {
     uLongf clen = compressBound((uLong)raw.size());
     vector<unsigned char> comp(clen);
     int status = -1;
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) == Z_OK) {
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 1) == Z_OK) {
         static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
         fwrite(sig, 1, 8, fp);
         unsigned char ihdr[13] = {(unsigned char)(width >> 24), (unsigned char)(width >> 16), (unsigned char)(width >> 8), (unsigned char)width,
@@ -449,9 +457,9 @@ RenderThread::~RenderThread() {
 }
 
 void RenderThread::send_message(RenderMessage message) {
-    pthread_mutex_lock(&parent->messages_lock);
+    if (!parent->hold_queue) pthread_mutex_lock(&parent->messages_lock); /* else the issuing thread already holds it */
     parent->messages.push_back(message);
-    pthread_mutex_unlock(&parent->messages_lock);
+    if (!parent->hold_queue) pthread_mutex_unlock(&parent->messages_lock);
     sem_post(&parent->messages_semaphore);
 }
 
@@ -591,6 +599,7 @@ RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_widt
     semaphore_passes_pending = 0;
     sample_base = 0;
     render_errors = 0;
+    hold_queue = false;
     next_global_sample = 0;
     mixed_rectangles = false;
     int n = get_optimal_thread_count();
@@ -681,7 +690,13 @@ void RenderEngine::perform_full_passes(int pass_count) { /* integrator.cpp:428-4
     global_tile_center_x = (width - tile_width) / 2.0;
     global_tile_center_y = (height - tile_height) / 2.0;
     stable_sort(tile_spots.begin(), tile_spots.end(), tile_compare);
+    /* the queue is held while the runs go in, so that the first worker to wake sees all of them and
+     * sizes its first batch by the whole job instead of by the few entries queued so far */
+    hold_queue = true;
+    pthread_mutex_lock(&messages_lock);
     for (auto spot : tile_spots) issue_pass_run(PassDescriptor(spot.first, spot.second, tile_width, tile_height), pass_count);
+    pthread_mutex_unlock(&messages_lock);
+    hold_queue = false;
 }
 
 /* Waits until every pass issued so far has been rendered.  Completion is counted in passes, under
