@@ -16,6 +16,6 @@ PT_CLI_TIMING=1 ./path_tracing_amd/bin/cli_render --stl $STL --output gpurun_out
 T1=$(date +%s.%N)
 echo "started at $T0, process gone at $T1" | tee gpurun_out/e2e/wall_abs.txt
 python3 -c "print(\"cli_render $S spp 1920x1080, 1343488 triangles: %.2f s wall\" % ($T1 - $T0))" | tee gpurun_out/e2e/wall.txt
-grep -a "timing" gpurun_out/e2e/cli.log | tee -a gpurun_out/e2e/wall.txt
+tr "\r" "\n" < gpurun_out/e2e/cli.log | grep -a -o "\[timing\].*" | tee -a gpurun_out/e2e/wall.txt
 tail -c 300 gpurun_out/e2e/cli.log
 rm -f $STL
