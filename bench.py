@@ -380,6 +380,12 @@ def main():
                                         "it exceeds what reaches HBM when the scene is cache-resident (see hbm_measured), so it is a "
                                         "ratio, not a fraction of a roofline",
                     "hbm_measured": hbm_meas,
+                    # from the same PMC passes (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, GRBM_GUI_ACTIVE): how busy the
+                    # SIMDs' vector issue is (a wave64 instruction = 2 cycles of a SIMD-32) and how many lanes work
+                    "valu_measured": ({"issue_utilisation": round(tr["closest_valu_issue_utilisation"], 4),
+                                       "lane_utilisation": round(tr["closest_valu_lane_utilisation"], 4),
+                                       "instructions_per_64_rays": round(tr["closest_valu_instructions_per_64_rays"], 1)}
+                                      if tr and "closest_valu_issue_utilisation" in tr else None),
                     "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
                     "rays_per_launch": round(rays_per_launch, 1),
                     "avg_launch_ms": round(ms_c / launches_c, 4),
