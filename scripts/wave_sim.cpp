@@ -240,3 +240,48 @@ void wave_sim_two(const pt_flat_scene* sc, uint64_t n, const float* o, const flo
 }
 
 }
+
+/* Packet model: rays [64k, 64k+64) form a packet that one wave would walk TOGETHER, visiting a
+ * node or testing a triangle once if any of its rays does.  Every ray is walked alone with the lane
+ * state machine; the packet's node visits and triangle tests are the unions over its rays.
+ * out[0] += sum over rays of node visits, out[1] += sum over rays of triangle tests,
+ * out[2] += sum over packets of distinct nodes, out[3] += sum over packets of distinct triangles,
+ * out[4] += packets. */
+#include <vector>
+#include <algorithm>
+extern "C" void packet_model(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, uint64_t* out) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    ptc::RootBox root;
+    root.mnx = sc->root_min[0]; root.mny = sc->root_min[1]; root.mnz = sc->root_min[2];
+    root.mxx = sc->root_max[0]; root.mxy = sc->root_max[1]; root.mxz = sc->root_max[2];
+    const bool scene_tame = ptc::root_is_tame(root);
+    std::vector<uint32_t> nodes, tris;
+    for (uint64_t base = 0; base + 64 <= n; base += 64) {
+        nodes.clear(); tris.clear();
+        for (uint64_t r = base; r < base + 64; r++) {
+            ptc::Lane l; CpuStack st;
+            l.r.ox = o[3 * r]; l.r.oy = o[3 * r + 1]; l.r.oz = o[3 * r + 2];
+            l.r.dx = d[3 * r]; l.r.dy = d[3 * r + 1]; l.r.dz = d[3 * r + 2];
+            ptc::ray_set_recip(l.r);
+            ptc::lane_start(l, sc->root_ref, root, scene_tame);
+            while (!ptc::lane_finished(l)) {
+                if (ptc::lane_has_leaf(l)) {
+                    uint32_t pos = ptc::lane_leaf_pos(l);
+                    ptc::TriData tr; mem.load_tri(pos, tr);
+                    ptc::lane_tri<false>(l, tr);
+                    tris.push_back(pos); out[1]++;
+                } else if (ptc::lane_has_node(l)) {
+                    nodes.push_back(l.cur); out[0]++;
+                    ptc::NodeData nd; mem.load_node(l.cur, nd);
+                    if (l.tame) ptc::lane_node<false, true>(l, nd, st); else ptc::lane_node<false, false>(l, nd, st);
+                } else if (l.sp > 0) {
+                    ptc::lane_pop<false>(l, st);
+                }
+            }
+        }
+        std::sort(nodes.begin(), nodes.end()); std::sort(tris.begin(), tris.end());
+        out[2] += std::unique(nodes.begin(), nodes.end()) - nodes.begin();
+        out[3] += std::unique(tris.begin(), tris.end()) - tris.begin();
+        out[4]++;
+    }
+}
