@@ -1,0 +1,86 @@
+"""Meshes that stress the arithmetic contract rather than the rays: coordinates beyond the range
+where the cheaper slab test may be used (every lane then takes the NaN-exact one) and whose
+products overflow, a mesh so small that the triangle test's absolute threshold cuts hits, zero-area and coincident triangles
+(exact ties), and one mesh spanning 30 orders of magnitude whose root box is beyond that range while
+its small triangles are still hit.  Host builder = oracle tree, lane
+emulation = oracle results on the CPU; the HIP path = oracle results through the C ABI (gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_hits_equal, load_emul, orc, pta, rays_hostile, rays_sphere
+
+
+def hostile_meshes():
+    base = pta.meshgen.standin_scene(3).astype(np.float32)
+    rng = np.random.default_rng(21)
+    meshes = {}
+    meshes["huge"] = (base * np.float32(1e31), 1e31)            # root box not "tame"; edge products overflow
+    meshes["tiny"] = (base * np.float32(2e-4), 2e-4)            # determinants on both sides of the 1e-8 threshold (utils.cpp:142): a third of the hits are cut
+    t = base.reshape(-1, 3, 3)
+    k = rng.integers(0, len(t), 60)
+    two_equal = t[k[:20]].copy(); two_equal[:, 1] = two_equal[:, 0]          # zero-area: two vertices equal
+    point = t[k[20:40]].copy(); point[:, 1] = point[:, 0]; point[:, 2] = point[:, 0]   # ... all three equal
+    dup = t[k[40:]].copy()                                                    # coincident copies: exact ties
+    meshes["degenerate"] = (np.concatenate([base, two_equal.reshape(-1, 9), point.reshape(-1, 9), dup.reshape(-1, 9),
+                                            dup.reshape(-1, 9)]).astype(np.float32), 1.0)
+    far = np.array([[2e30, 0, 0, 0, 2e30, 0, 0, 0, 2e30], [-1e25, -1e25, -5, 1e25, -1e25, -5, 0, 1e25, -5]], np.float32)   # 2e30: the root box is not "tame"
+    meshes["mixed_scale"] = (np.concatenate([base, far]).astype(np.float32), 1.0)
+    return meshes
+
+
+def ray_sets(tris, scale, n=6000):
+    o, d = rays_sphere(n, seed=31)
+    ho, hd = rays_hostile(tris, n, seed=32)
+    s = np.float32(scale)
+    with np.errstate(over="ignore", invalid="ignore"):
+        return {"sphere": (o * s, d), "hostile": (ho * s, hd)}
+
+
+def shadow_dist(n):
+    """Light distances on both sides of 1 (below 1 the reference's answer depends on the closest hit's v)."""
+    rng = np.random.default_rng(33)
+    return np.where(rng.random(n) < 0.5, rng.random(n), 1.0 + 4.0 * rng.random(n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["huge", "tiny", "degenerate", "mixed_scale"])
+def test_host_tree_and_lane_walk(name):
+    tris, scale = hostile_meshes()[name]
+    host = pta.HostScene(tris)
+    oracle = orc.Scene(tris)
+    (n1, l1), (n2, l2) = oracle.tree_dump(), host.tree_dump()
+    assert np.array_equal(n1.view(np.uint8), n2.view(np.uint8)) and np.array_equal(l1, l2), "the host builder's tree differs from the oracle's"
+    E = load_emul()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for rname, (o, d) in ray_sets(tris, scale).items():
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        n = len(o)
+        idx = np.empty(n, np.int32); t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        worst = E.emul_raycast_closest(C.byref(host.flat), n, p(o), p(d), p(idx), p(t), p(u), p(v), None)
+        assert 0 <= worst <= 60
+        assert_hits_equal((idx, t, u, v), oracle.raycast(o, d), f"{name}/{rname}")
+        dist = shadow_dist(n)
+        vis = np.empty(n, np.uint8)
+        assert E.emul_raycast_shadow(C.byref(host.flat), n, p(o), p(d), p(dist), p(vis)) >= 0
+        assert np.array_equal(vis, oracle.shadow_visible(o, d, dist)), f"{name}/{rname} shadow"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["huge", "tiny", "degenerate", "mixed_scale"])
+def test_gpu_matches_oracle(name):
+    tris, scale = hostile_meshes()[name]
+    host = pta.HostScene(tris)
+    oracle = orc.Scene(tris)
+    gpu = pta.GpuScene(host, 0)
+    some_hit = False
+    for rname, (o, d) in ray_sets(tris, scale).items():
+        want = oracle.raycast(o, d)
+        assert_hits_equal(gpu.raycast_closest(o, d), want, f"{name}/{rname}")
+        some_hit = some_hit or (want[0] >= 0).any()
+        dist = shadow_dist(len(o))
+        assert np.array_equal(gpu.raycast_shadow(o, d, dist), oracle.shadow_visible(o, d, dist)), f"{name}/{rname} shadow"
+        bound = np.where(want[0] >= 0, want[1] * np.float32(1.5), np.float32(1.0)).astype(np.float32)
+        assert np.array_equal(gpu.raycast_shadow(o, d, bound, bounded=True), oracle.shadow_visible(o, d, bound, bounded=True)), f"{name}/{rname} bounded"
+    # every product of two edges of the huge mesh overflows, so there every test is a miss on both sides
+    assert some_hit or name == "huge", "the ray sets never hit this mesh: the case tests nothing"
