@@ -2,7 +2,7 @@
 where the cheaper slab test may be used (every lane then takes the NaN-exact one) and whose
 products overflow, a mesh so small that the triangle test's absolute threshold cuts hits, zero-area and coincident triangles
 (exact ties), and one mesh spanning 30 orders of magnitude whose root box is beyond that range while
-its small triangles are still hit.  Host builder = oracle tree, lane
+its small triangles are still hit; and random triangle soups of 1 to 5000 triangles.  Host builder = oracle tree, lane
 emulation = oracle results on the CPU; the HIP path = oracle results through the C ABI (gpu)."""
 import ctypes as C
 
@@ -27,7 +27,20 @@ def hostile_meshes():
                                             dup.reshape(-1, 9)]).astype(np.float32), 1.0)
     far = np.array([[2e30, 0, 0, 0, 2e30, 0, 0, 0, 2e30], [-1e25, -1e25, -5, 1e25, -1e25, -5, 0, 1e25, -5]], np.float32)   # 2e30: the root box is not "tame"
     meshes["mixed_scale"] = (np.concatenate([base, far]).astype(np.float32), 1.0)
+    # Random triangle soups: boxes overlap everywhere, so the walk takes the "origin inside both
+    # children" branch (kdtree.cpp:324-342) and the far-side rule far more often than on a surface.
+    for n in (1, 2, 9, 300, 5000):
+        c = rng.random((n, 1, 3)).astype(np.float32) * 2 - 1
+        size = np.float32(10.0) ** rng.uniform(-2.5, 0.0, (n, 1, 1)).astype(np.float32)
+        soup = c + (rng.normal(size=(n, 3, 3)).astype(np.float32) * size)
+        if n >= 300:   # long thin slivers across the whole cloud
+            soup[:n // 10, 1] = soup[:n // 10, 0] + np.float32(1e-4) * rng.normal(size=(n // 10, 3)).astype(np.float32)
+            soup[:n // 10, 2] = -soup[:n // 10, 0]
+        meshes["soup%d" % n] = (soup.reshape(-1, 9).astype(np.float32), 1.0)
     return meshes
+
+
+MESH_NAMES = ["huge", "tiny", "degenerate", "mixed_scale", "soup1", "soup2", "soup9", "soup300", "soup5000"]
 
 
 def ray_sets(tris, scale, n=6000):
@@ -44,7 +57,7 @@ def shadow_dist(n):
     return np.where(rng.random(n) < 0.5, rng.random(n), 1.0 + 4.0 * rng.random(n)).astype(np.float32)
 
 
-@pytest.mark.parametrize("name", ["huge", "tiny", "degenerate", "mixed_scale"])
+@pytest.mark.parametrize("name", MESH_NAMES)
 def test_host_tree_and_lane_walk(name):
     tris, scale = hostile_meshes()[name]
     host = pta.HostScene(tris)
@@ -67,7 +80,7 @@ def test_host_tree_and_lane_walk(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["huge", "tiny", "degenerate", "mixed_scale"])
+@pytest.mark.parametrize("name", MESH_NAMES)
 def test_gpu_matches_oracle(name):
     tris, scale = hostile_meshes()[name]
     host = pta.HostScene(tris)
@@ -84,3 +97,24 @@ def test_gpu_matches_oracle(name):
         assert np.array_equal(gpu.raycast_shadow(o, d, bound, bounded=True), oracle.shadow_visible(o, d, bound, bounded=True)), f"{name}/{rname} bounded"
     # every product of two edges of the huge mesh overflows, so there every test is a miss on both sides
     assert some_hit or name == "huge", "the ray sets never hit this mesh: the case tests nothing"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["soup300", "degenerate"])
+def test_gpu_render_matches_oracle(name):
+    """The whole bounce loop on a mesh where mirror paths run deep (a soup reflects into itself) and
+    on one with exact ties: same ray counts, same pass counts, radiance within the summation-order
+    tolerance of the render parity test."""
+    tris, _ = hostile_meshes()[name]
+    oracle = orc.Scene(tris)
+    gpu = pta.GpuScene(pta.HostScene(tris), 0)
+    W, H, S = 64, 48, 3
+    want_rgb, want_p, want_counts = oracle.render(orc.cli_camera(dof_aperture=0.1, dof_distance=4.5), orc.cli_lights(), W, H, None, 0, S, seed=9)
+    film = pta.Film(gpu, W, H)
+    st = film.render(pta.cli_camera(dof_aperture=0.1, dof_distance=4.5), pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=9)
+    rgb, passes = film.read()
+    assert np.array_equal(passes, want_p)
+    assert st.closest_rays == int(want_counts[0]) and st.shadow_rays == int(want_counts[1])
+    assert st.closest_rays > 1.5 * W * H * S, "paths should bounce on this mesh"
+    err = np.abs(rgb - want_rgb)
+    assert (err <= 1e-5 * np.maximum(np.abs(want_rgb), 1.0)).all(), f"max err {err.max()}"
