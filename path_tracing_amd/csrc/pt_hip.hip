@@ -107,6 +107,9 @@ struct RaySoAW {
 #ifndef REFILL_MIN_ANY
 #define REFILL_MIN_ANY 32
 #endif
+#ifndef TRACE_WAVES_PER_EU_2
+#define TRACE_WAVES_PER_EU_2 7 /* the two-triangles-per-round kernels hold a second record: 72 registers instead of 64 */
+#endif
 #ifndef TRACE_WAVES_PER_EU
 #define TRACE_WAVES_PER_EU 8 /* register budget of the trace kernels: waves per SIMD the compiler must allow
                                 (6 -> 8: the same 56-57 registers, but a schedule that is 2 % faster) */
@@ -217,8 +220,8 @@ struct TraceArgs {
  * one atomic on the queue head per chunk).  The loop ends when the queue is empty and every
  * lane is idle, so the grid always drains.
  */
-template <int MODE>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES_PER_EU))) void k_trace(DScene sc, TraceArgs a) {
+template <int MODE, int TPR = 1>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED);
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
     __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
@@ -278,6 +281,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
      * and the start of new rays run while they are in flight. */
     float4 q0, q1, q2, q3;                    /* the lane's record for this round; meaningful where rec_* says so */
     bool rec_tri = false, rec_node = false;   /* what was loaded for this lane: a triangle / an interior node */
+    /* TPR == 2 (scenes with large leaves): a lane with a pending leaf also takes the record that
+     * follows its triangle in the array and tests it in the same round if the leaf goes on */
+    float4 q4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q5 = q4, q6 = q4;
+    bool rec_tri2 = false;
     bool starting = false;                    /* this lane's registers are receiving a new ray */
     uint32_t new_ray = 0;
 
@@ -288,6 +295,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
         asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
                            "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
         asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist), "v"(tgt));
+        if (TPR == 2) asm volatile("" :: "v"(q4.x), "v"(q4.y), "v"(q4.z), "v"(q4.w), "v"(q5.x), "v"(q5.y), "v"(q5.z), "v"(q5.w), "v"(q6.x), "v"(q6.y), "v"(q6.w));
 
         /* ---- start the refilled lanes (they take their first record with everyone else below) ---- */
         bool defer = false;
@@ -324,6 +332,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             tr.e2x = q1.z; tr.e2y = q1.w; tr.e2z = q2.x;
             tr.mesh_index = __float_as_uint(q2.y); tr.leaf_remaining = __float_as_uint(q2.w);
             lane_tri<ANY>(L, tr);
+            if (TPR == 2 && rec_tri2 && lane_has_leaf(L)) {   /* the leaf goes on: its next triangle, same rules */
+                tr.p0x = q4.x; tr.p0y = q4.y; tr.p0z = q4.z;
+                tr.e1x = q4.w; tr.e1y = q5.x; tr.e1z = q5.y;
+                tr.e2x = q5.z; tr.e2y = q5.w; tr.e2z = q6.x;
+                tr.mesh_index = __float_as_uint(q6.y); tr.leaf_remaining = __float_as_uint(q6.w);
+                lane_tri<ANY>(L, tr);
+            }
         }
         {
             NodeData nd;
@@ -357,6 +372,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TRA
             const float4* rec = (const float4*)(sc.geom + off);
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             if (rec_node) q3 = rec[3];
+            if (TPR == 2) {
+                rec_tri2 = rec_tri && lane_leaf_pos(L) + 1u < sc.n_tris;
+                if (rec_tri2) { q4 = rec[3]; q5 = rec[4]; q6 = rec[5]; }
+            }
         }
 
         /* ---- retire finished rays ---- */
@@ -924,6 +943,7 @@ struct pt_scene {
     uint32_t* d_defer = nullptr; /* deferred shadow rays of pt_raycast_shadow_dev */
     uint64_t defer_cap = 0;
     int grid_closest = 0, grid_any = 0; /* resident blocks of the persistent trace kernels */
+    int tris_per_round = 1;             /* 2: the trace kernels that test two triangles of a leaf per round (large leaves) */
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
     double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
@@ -974,7 +994,8 @@ struct ScopedTimer {
 };
 
 /* Walks the flattened tree once on the host so that no kernel ever follows a bad reference. */
-static int validate_flat(const pt_flat_scene* f) {
+static int validate_flat(const pt_flat_scene* f, uint64_t* n_leaves) {
+    *n_leaves = 0;
     if (f->n_tris >= PT_MAX_TRIANGLES) return fail(PT_ERR_LIMIT, "too many triangles (limit 2^26 - 64)");
     if (f->n_tris == 0) return PT_OK;
     if (!f->tris || !f->shade) return fail(PT_ERR_INVALID, "null triangle arrays");
@@ -998,6 +1019,7 @@ static int validate_flat(const pt_flat_scene* f) {
             for (uint32_t k = 0; k < count; k++)
                 if (f->tris[start + k].leaf_remaining != count - 1 - k) return fail(PT_ERR_INVALID, "leaf_remaining does not count down to the leaf's end");
             tri_total += count;
+            *n_leaves += 1;
             continue;
         }
         if (it.ref >= f->n_nodes) return fail(PT_ERR_INVALID, "node reference out of range");
@@ -1040,7 +1062,8 @@ int pt_device_prepare(int device) {
 int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     if (!flat || !out) return fail(PT_ERR_INVALID, "null argument");
     *out = nullptr;
-    int rc = validate_flat(flat);
+    uint64_t n_leaves = 0;
+    int rc = validate_flat(flat, &n_leaves);
     if (rc != PT_OK) return rc;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
@@ -1073,6 +1096,11 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     s->d.shade = (const float4*)s->d_shade;
     s->d.root_ref = flat->root_ref;
     s->d.n_tris = (uint32_t)flat->n_tris;
+    /* Leaves of sixteen and more triangles on average (the reference's depth cap, kdtree.cpp:67,
+     * at tens of millions of triangles): the kernels that test two triangles per round pay there
+     * and cost a little on ordinary trees.  PT_TRIS_PER_ROUND = 1 / 2 overrides. */
+    s->tris_per_round = (n_leaves > 0 && flat->n_tris >= 16 * n_leaves) ? 2 : 1;
+    if (const char* e = getenv("PT_TRIS_PER_ROUND")) { int v = atoi(e); if (v == 1 || v == 2) s->tris_per_round = v; }
     if (init_trace_launch(s) != PT_OK) return cleanup(PT_ERR_DEVICE);
     {   /* the address of this device's copy of the static scratch array (the device is current) */
         void* p = nullptr;
@@ -1142,7 +1170,9 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     a.spill = here.spill;
     if (a.count_mul == 0) a.count_mul = 1;
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW, here.stream);
-    hipLaunchKernelGGL(k_trace<MODE>, dim3(trace_grid(s, MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED)), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    const dim3 grid(trace_grid(s, MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED));
+    if (s->tris_per_round == 2) hipLaunchKernelGGL((k_trace<MODE, 2>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    else hipLaunchKernelGGL((k_trace<MODE, 1>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -1151,8 +1181,13 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
  * allocates the stack spill area for the larger of them. */
 static int init_trace_launch(pt_scene* s) {
     int per_cu_c = 0, per_cu_a = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT>, TRACE_BLOCK, 0));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY>, TRACE_BLOCK, 0));
+    if (s->tris_per_round == 2) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT, 2>, TRACE_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 2>, TRACE_BLOCK, 0));
+    } else {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT, 1>, TRACE_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 1>, TRACE_BLOCK, 0));
+    }
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) { per_cu_c = v; per_cu_a = v; } }
     per_cu_c = std::max(1, std::min(per_cu_c, 8));
     per_cu_a = std::max(1, std::min(per_cu_a, 8));

@@ -274,3 +274,27 @@ def test_cast_rays_matches_oracle(scene_medium):
     assert (np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1.0)).all()
     with pytest.raises(Exception):
         sc.gpu.cast_rays(pta.cli_camera(), pta.cli_lights(), o[:4], d[:4], recursions=11)
+
+
+def test_two_triangles_per_round_kernels(scene_small, scene_medium, monkeypatch):
+    """Scenes whose leaves hold sixteen and more triangles on average get trace kernels that test
+    two triangles of a leaf per round; PT_TRIS_PER_ROUND=2 selects them for any scene.  Same
+    results, bit for bit, on every ray set, for closest hit, both shadow tests and a render."""
+    monkeypatch.setenv("PT_TRIS_PER_ROUND", "2")
+    for sc in (scene_small, scene_medium):
+        gpu = pta.GpuScene(sc.host, 0)
+        for name, (o, d) in all_ray_sets(sc.tris, 6000).items():
+            want = sc.oracle.raycast(o, d)
+            assert_hits_equal(gpu.raycast_closest(o, d), want, f"two per round/{name}")
+            rng = np.random.default_rng(11)
+            dist = np.where(rng.random(len(o)) < 0.5, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
+            assert np.array_equal(gpu.raycast_shadow(o, d, dist), sc.oracle.shadow_visible(o, d, dist)), name
+            bound = np.where(want[0] >= 0, want[1] * np.float32(1.5), np.float32(1.0)).astype(np.float32)
+            assert np.array_equal(gpu.raycast_shadow(o, d, bound, bounded=True), sc.oracle.shadow_visible(o, d, bound, bounded=True)), name
+    W, H, S = 64, 48, 3
+    film_a, film_b = pta.Film(gpu, W, H), pta.Film(scene_medium.gpu, W, H)
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    st_a = film_a.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=4)
+    st_b = film_b.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=4)
+    assert (st_a.closest_rays, st_a.shadow_rays) == (st_b.closest_rays, st_b.shadow_rays)
+    assert np.array_equal(film_a.read()[0].view(np.uint32), film_b.read()[0].view(np.uint32))
