@@ -214,6 +214,8 @@ struct TraceArgs {
  *     node, fetched through one per-lane address so that the same four load instructions
  *     serve both kinds of lane.
  * Stack traffic is LDS only on the common path and needs no wait on global memory.
+ * TPR = 2 (scenes with large leaves) adds the record after a lane's triangle to the group and
+ * tests it in the same round when the leaf goes on; order and comparisons are unchanged.
  *
  * Lanes whose ray is finished write their result and go idle; when enough lanes are idle the
  * wave hands them the next rays of its chunk (TRACE_CHUNK..TRACE_MAX_CHUNK_MUL*TRACE_CHUNK consecutive rays,
