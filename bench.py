@@ -354,8 +354,10 @@ def main():
                                 "l2_hit_rate": round(tr.get("closest_l2_hit_rate", float("nan")), 4),
                                 "source": "profiles/traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                           "2*FETCH_SIZE + WRITE_SIZE) x this run's rays per second in the kernel" % key}
-                if scene_bytes > INFINITY_CACHE_BYTES:
+                if scene_bytes > INFINITY_CACHE_BYTES and algorithmic <= HBM_PEAK_GBS:
                     # the scene streams from HBM: the algorithmic bytes are priced against the HBM peak
+                    # (should the caches ever serve so much of them that this exceeds the peak, it stops
+                    # being a roofline and the load path below is quoted instead)
                     roof = {"bound": "hbm", "achieved": round(algorithmic, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(algorithmic / HBM_PEAK_GBS, 5), "traffic": traffic}
                 else:

@@ -8,7 +8,7 @@ how bench.py looks its own workload up.
 
 HBM-side bytes of the closest-hit trace kernel per ray = (2 * FETCH_SIZE + WRITE_SIZE) / rays,
 where FETCH_SIZE and WRITE_SIZE are the rocprofv3 counters (kilobytes) summed over every
-dispatch of k_trace<1> in their own PMC passes, FETCH_SIZE doubled as the gfx950 correction for
+dispatch of k_trace<1, *> in their own PMC passes, FETCH_SIZE doubled as the gfx950 correction for
 16-byte-per-lane loads prescribes, and rays = closest rays per step * (steps + warmup) of the
 profiled bench command (taken from its JSON line).
 """
@@ -42,7 +42,7 @@ def main():
     line = json.loads(open(os.path.join(root, name)).read().strip().splitlines()[-1])
     steps_total = line["steps"] + line["warmup"]
     out = {"source": os.path.basename(root.rstrip("/")), "bench_line": {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}}
-    for name, kernel, count_key in (("closest", "k_trace<1>", "closest_rays"), ("shadow", "k_trace<2>", "shadow_rays")):
+    for name, kernel, count_key in (("closest", "k_trace<1", "closest_rays"), ("shadow", "k_trace<2", "shadow_rays")):
         # shadow rays: the traced ones (zero-weight light samples are counted but not traced)
         rays = line.get(count_key + "_traced", line[count_key]) / line["steps"] * steps_total
         fetch_kb, nd = counter_sum(root, "FETCH_SIZE", kernel)
