@@ -107,6 +107,9 @@ struct RaySoAW {
 #ifndef REFILL_MIN_ANY
 #define REFILL_MIN_ANY 32
 #endif
+#ifndef TRACE_WAVES_PER_EU_3
+#define TRACE_WAVES_PER_EU_3 6 /* three triangles per round: 80 registers */
+#endif
 #ifndef TRACE_WAVES_PER_EU_2
 #define TRACE_WAVES_PER_EU_2 7 /* the two-triangles-per-round kernels hold a second record: 72 registers instead of 64 */
 #endif
@@ -214,8 +217,8 @@ struct TraceArgs {
  *     node, fetched through one per-lane address so that the same four load instructions
  *     serve both kinds of lane.
  * Stack traffic is LDS only on the common path and needs no wait on global memory.
- * TPR = 2 (scenes with large leaves) adds the record after a lane's triangle to the group and
- * tests it in the same round when the leaf goes on; order and comparisons are unchanged.
+ * TPR = 2, 3 (scenes with large leaves) adds the TPR-1 records after a lane's triangle to the
+ * group and tests them in the same round while the leaf goes on; order and comparisons are unchanged.
  *
  * Lanes whose ray is finished write their result and go idle; when enough lanes are idle the
  * wave hands them the next rays of its chunk (TRACE_CHUNK..TRACE_MAX_CHUNK_MUL*TRACE_CHUNK consecutive rays,
@@ -223,7 +226,7 @@ struct TraceArgs {
  * lane is idle, so the grid always drains.
  */
 template <int MODE, int TPR = 1>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU))) void k_trace(DScene sc, TraceArgs a) {
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 1 ? TRACE_WAVES_PER_EU : TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU_3))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED);
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
     __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
@@ -283,10 +286,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
      * and the start of new rays run while they are in flight. */
     float4 q0, q1, q2, q3;                    /* the lane's record for this round; meaningful where rec_* says so */
     bool rec_tri = false, rec_node = false;   /* what was loaded for this lane: a triangle / an interior node */
-    /* TPR == 2 (scenes with large leaves): a lane with a pending leaf also takes the record that
-     * follows its triangle in the array and tests it in the same round if the leaf goes on */
-    float4 q4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q5 = q4, q6 = q4;
-    bool rec_tri2 = false;
+    /* TPR > 1 (scenes with large leaves): a lane with a pending leaf also takes the TPR-1 records
+     * that follow its triangle in the array and tests them in the same round while the leaf goes on */
+    float4 qx[TPR > 1 ? TPR - 1 : 1][3];
+#pragma unroll
+    for (int k = 0; k < TPR - 1; k++) { qx[k][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qx[k][1] = qx[k][0]; qx[k][2] = qx[k][0]; }
+    int rec_more = 0;                         /* records loaded after the lane's triangle */
     bool starting = false;                    /* this lane's registers are receiving a new ray */
     uint32_t new_ray = 0;
 
@@ -297,7 +302,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
         asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
                            "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
         asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist), "v"(tgt));
-        if (TPR == 2) asm volatile("" :: "v"(q4.x), "v"(q4.y), "v"(q4.z), "v"(q4.w), "v"(q5.x), "v"(q5.y), "v"(q5.z), "v"(q5.w), "v"(q6.x), "v"(q6.y), "v"(q6.w));
+#pragma unroll
+        for (int k = 0; k < TPR - 1; k++)
+            asm volatile("" :: "v"(qx[k][0].x), "v"(qx[k][0].y), "v"(qx[k][0].z), "v"(qx[k][0].w), "v"(qx[k][1].x), "v"(qx[k][1].y), "v"(qx[k][1].z),
+                               "v"(qx[k][1].w), "v"(qx[k][2].x), "v"(qx[k][2].y), "v"(qx[k][2].w));
 
         /* ---- start the refilled lanes (they take their first record with everyone else below) ---- */
         bool defer = false;
@@ -334,12 +342,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             tr.e2x = q1.z; tr.e2y = q1.w; tr.e2z = q2.x;
             tr.mesh_index = __float_as_uint(q2.y); tr.leaf_remaining = __float_as_uint(q2.w);
             lane_tri<ANY>(L, tr);
-            if (TPR == 2 && rec_tri2 && lane_has_leaf(L)) {   /* the leaf goes on: its next triangle, same rules */
-                tr.p0x = q4.x; tr.p0y = q4.y; tr.p0z = q4.z;
-                tr.e1x = q4.w; tr.e1y = q5.x; tr.e1z = q5.y;
-                tr.e2x = q5.z; tr.e2y = q5.w; tr.e2z = q6.x;
-                tr.mesh_index = __float_as_uint(q6.y); tr.leaf_remaining = __float_as_uint(q6.w);
-                lane_tri<ANY>(L, tr);
+#pragma unroll
+            for (int k = 0; k < TPR - 1; k++) {
+                if (k < rec_more && lane_has_leaf(L)) {   /* the leaf goes on: its next triangle, same rules */
+                    tr.p0x = qx[k][0].x; tr.p0y = qx[k][0].y; tr.p0z = qx[k][0].z;
+                    tr.e1x = qx[k][0].w; tr.e1y = qx[k][1].x; tr.e1z = qx[k][1].y;
+                    tr.e2x = qx[k][1].z; tr.e2y = qx[k][1].w; tr.e2z = qx[k][2].x;
+                    tr.mesh_index = __float_as_uint(qx[k][2].y); tr.leaf_remaining = __float_as_uint(qx[k][2].w);
+                    lane_tri<ANY>(L, tr);
+                }
             }
         }
         {
@@ -374,9 +385,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             const float4* rec = (const float4*)(sc.geom + off);
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
             if (rec_node) q3 = rec[3];
-            if (TPR == 2) {
-                rec_tri2 = rec_tri && lane_leaf_pos(L) + 1u < sc.n_tris;
-                if (rec_tri2) { q4 = rec[3]; q5 = rec[4]; q6 = rec[5]; }
+            if (TPR > 1) {
+                const uint32_t after = sc.n_tris - 1u - lane_leaf_pos(L);   /* records that follow in the array */
+                rec_more = rec_tri ? (int)min(after, (uint32_t)(TPR - 1)) : 0;
+#pragma unroll
+                for (int k = 0; k < TPR - 1; k++)
+                    if (k < rec_more) { qx[k][0] = rec[3 + 3 * k]; qx[k][1] = rec[4 + 3 * k]; qx[k][2] = rec[5 + 3 * k]; }
             }
         }
 
@@ -945,7 +959,7 @@ struct pt_scene {
     uint32_t* d_defer = nullptr; /* deferred shadow rays of pt_raycast_shadow_dev */
     uint64_t defer_cap = 0;
     int grid_closest = 0, grid_any = 0; /* resident blocks of the persistent trace kernels */
-    int tris_per_round = 1;             /* 2: the trace kernels that test two triangles of a leaf per round (large leaves) */
+    int tris_per_round = 1;             /* 2, 3: the trace kernels that test that many triangles of a leaf per round (large leaves) */
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
     double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
@@ -1099,10 +1113,11 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     s->d.root_ref = flat->root_ref;
     s->d.n_tris = (uint32_t)flat->n_tris;
     /* Leaves of sixteen and more triangles on average (the reference's depth cap, kdtree.cpp:67,
-     * at tens of millions of triangles): the kernels that test two triangles per round pay there
-     * and cost a little on ordinary trees.  PT_TRIS_PER_ROUND = 1 / 2 overrides. */
-    s->tris_per_round = (n_leaves > 0 && flat->n_tris >= 16 * n_leaves) ? 2 : 1;
-    if (const char* e = getenv("PT_TRIS_PER_ROUND")) { int v = atoi(e); if (v == 1 || v == 2) s->tris_per_round = v; }
+     * at tens of millions of triangles): the kernels that test two or three triangles per round
+     * pay there and cost on ordinary trees (measured: 41 per leaf +15 % with three, 10 per leaf
+     * -4 % with two, 5.6 per leaf -14 %).  PT_TRIS_PER_ROUND = 1 / 2 / 3 overrides. */
+    s->tris_per_round = n_leaves == 0 ? 1 : flat->n_tris >= 24 * n_leaves ? 3 : flat->n_tris >= 16 * n_leaves ? 2 : 1;
+    if (const char* e = getenv("PT_TRIS_PER_ROUND")) { int v = atoi(e); if (v >= 1 && v <= 3) s->tris_per_round = v; }
     if (init_trace_launch(s) != PT_OK) return cleanup(PT_ERR_DEVICE);
     {   /* the address of this device's copy of the static scratch array (the device is current) */
         void* p = nullptr;
@@ -1174,6 +1189,7 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW, here.stream);
     const dim3 grid(trace_grid(s, MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED));
     if (s->tris_per_round == 2) hipLaunchKernelGGL((k_trace<MODE, 2>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    else if (s->tris_per_round == 3) hipLaunchKernelGGL((k_trace<MODE, 3>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     else hipLaunchKernelGGL((k_trace<MODE, 1>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     HIP_TRY(hipGetLastError());
     return PT_OK;
@@ -1186,6 +1202,9 @@ static int init_trace_launch(pt_scene* s) {
     if (s->tris_per_round == 2) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT, 2>, TRACE_BLOCK, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 2>, TRACE_BLOCK, 0));
+    } else if (s->tris_per_round == 3) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT, 3>, TRACE_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 3>, TRACE_BLOCK, 0));
     } else {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT, 1>, TRACE_BLOCK, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 1>, TRACE_BLOCK, 0));

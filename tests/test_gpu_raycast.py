@@ -276,16 +276,17 @@ def test_cast_rays_matches_oracle(scene_medium):
         sc.gpu.cast_rays(pta.cli_camera(), pta.cli_lights(), o[:4], d[:4], recursions=11)
 
 
-def test_two_triangles_per_round_kernels(scene_small, scene_medium, monkeypatch):
+@pytest.mark.parametrize("per_round", ["2", "3"])
+def test_several_triangles_per_round_kernels(scene_small, scene_medium, monkeypatch, per_round):
     """Scenes whose leaves hold sixteen and more triangles on average get trace kernels that test
-    two triangles of a leaf per round; PT_TRIS_PER_ROUND=2 selects them for any scene.  Same
+    two or three triangles of a leaf per round; PT_TRIS_PER_ROUND selects them for any scene.  Same
     results, bit for bit, on every ray set, for closest hit, both shadow tests and a render."""
-    monkeypatch.setenv("PT_TRIS_PER_ROUND", "2")
+    monkeypatch.setenv("PT_TRIS_PER_ROUND", per_round)
     for sc in (scene_small, scene_medium):
         gpu = pta.GpuScene(sc.host, 0)
         for name, (o, d) in all_ray_sets(sc.tris, 6000).items():
             want = sc.oracle.raycast(o, d)
-            assert_hits_equal(gpu.raycast_closest(o, d), want, f"two per round/{name}")
+            assert_hits_equal(gpu.raycast_closest(o, d), want, f"{per_round} per round/{name}")
             rng = np.random.default_rng(11)
             dist = np.where(rng.random(len(o)) < 0.5, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
             assert np.array_equal(gpu.raycast_shadow(o, d, dist), sc.oracle.shadow_visible(o, d, dist)), name
