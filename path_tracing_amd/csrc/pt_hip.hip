@@ -104,6 +104,9 @@ struct RaySoAW {
 #ifndef REFILL_MIN_CLOSEST
 #define REFILL_MIN_CLOSEST 16
 #endif
+#ifndef REFILL_MIN_CLOSEST_LARGE_LEAVES
+#define REFILL_MIN_CLOSEST_LARGE_LEAVES 32 /* the several-triangles-per-round kernels: 8 / 16 / 32 give 376 / 352 / 343 ms on the 21.5 M-triangle scene */
+#endif
 #ifndef REFILL_MIN_ANY
 #define REFILL_MIN_ANY 32
 #endif
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
         starting = false;
         if (idle) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (!exhausted && (n_idle >= (ANY ? REFILL_MIN_ANY : REFILL_MIN_CLOSEST) || idle == ~0ull)) {
+            if (!exhausted && (n_idle >= (ANY ? REFILL_MIN_ANY : TPR > 1 ? REFILL_MIN_CLOSEST_LARGE_LEAVES : REFILL_MIN_CLOSEST) || idle == ~0ull)) {
                 if (pool_next >= pool_end) {
 #if TRACE_XCD_SUPER
                     uint32_t c = total_chunks;
