@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the ray-casting hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2], the configuration the metric "Mrays/s (all bounces)" is
@@ -88,11 +88,61 @@ def measured_traffic(key):
         return None
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process starts the N
+    ranks itself, one fresh child per GPU (the reference's RenderEngine spawns its N workers
+    itself, integrator.cpp:361-378), before anything here has imported torch or touched a GPU.
+    It relays rank 0's JSON line and exits non-zero if any rank does."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line0 = b""
+    try:
+        line0 = procs[0].stdout.read()      # rank 0 prints the one JSON line; stderr passes through
+        pending = list(procs)
+        status = 0
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    # one rank failed: the others would wait for it in the next collective
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if status == 0:
+        sys.stdout.write(line0.decode())
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(line0.decode())
+        print("[bench] a rank exited with status %d" % status, file=sys.stderr)
+    return status
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("[bench] --gpus %d but the launcher started %d rank(s): running %d" % (args.gpus, world, world), file=sys.stderr)
     import torch
     import torch.distributed as dist
 

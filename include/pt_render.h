@@ -222,7 +222,8 @@ struct RenderThread { /* integrator.h:67-89: one per GPU */
     Integrator* integrator;
     RenderThread(RenderEngine* parent, int device);
     ~RenderThread();
-    void send_message(RenderMessage message);
+    /* queue_locked: the caller holds parent->messages_lock (only RenderEngine::perform_full_passes does) */
+    void send_message(RenderMessage message, bool queue_locked = false);
     void kill_immediately();
     static void* render_thread_main(void* cookie);
 };
@@ -252,7 +253,7 @@ struct RenderEngine { /* integrator.h:91-127 */
     /* `count` passes of one rectangle as ONE queue entry (perform_full_passes issues a tile's
      * passes this way: half a million queue entries for 1000 samples of a 1080p frame would cost
      * more host time than the GPUs need for a tenth of the render) */
-    void issue_pass_run(PassDescriptor desc, int count);
+    void issue_pass_run(PassDescriptor desc, int count, bool queue_locked = false);
     void perform_full_pass();
     void perform_full_passes(int pass_count);
     void sync();
@@ -269,7 +270,6 @@ struct RenderEngine { /* integrator.h:91-127 */
     std::string last_error;
     std::string last_reduce_how;
     uint32_t next_global_sample; /* see issue_pass_desc */
-    bool hold_queue;             /* perform_full_passes holds messages_lock while it queues its runs */
     bool mixed_rectangles;
     /* Continues a render: zero(), then the canvas' accumulators become the first worker's film
      * and every rectangle's sample stream starts after the samples the canvas already holds

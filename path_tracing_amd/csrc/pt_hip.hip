@@ -1349,12 +1349,11 @@ extern "C" {
 #define PICK_HEAD_WORDS 256u
 static int raycast_closest_small(pt_scene* s, uint32_t n, const float* const* in6, int32_t* idx, float* t, float* u, float* v) {
     std::lock_guard<std::mutex> guard(s->pick_mu);
-    if (!s->pick_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&s->pick_stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc((void**)&s->d_pick, (PICK_HEAD_WORDS + (size_t)PICK_GRID * TRACE_BLOCK * (STACK_MAX_CLOSEST - STACK_LDS)) * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc((void**)&s->h_pick, 10 * PICK_MAX_RAYS * sizeof(float), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&s->h_pick_dev, s->h_pick, 0));
-    }
+    /* each resource is made if it is missing, so a call that failed half-way is completed by the next */
+    if (!s->pick_stream) HIP_TRY(hipStreamCreateWithFlags(&s->pick_stream, hipStreamNonBlocking));
+    if (!s->d_pick) HIP_TRY(hipMalloc((void**)&s->d_pick, (PICK_HEAD_WORDS + (size_t)PICK_GRID * TRACE_BLOCK * (STACK_MAX_CLOSEST - STACK_LDS)) * sizeof(uint32_t)));
+    if (!s->h_pick) HIP_TRY(hipHostMalloc((void**)&s->h_pick, 10 * PICK_MAX_RAYS * sizeof(float), hipHostMallocMapped));
+    if (!s->h_pick_dev) HIP_TRY(hipHostGetDevicePointer((void**)&s->h_pick_dev, s->h_pick, 0));
     float* h = s->h_pick;
     for (int k = 0; k < 6; k++) memcpy(h + k * PICK_MAX_RAYS, in6[k], n * sizeof(float));
     float* d = s->h_pick_dev;
@@ -1467,7 +1466,19 @@ struct pt_film {
     float4* d_film = nullptr;
     bool owns = false;
     RenderLane lane[RENDER_LANES]; /* render scratch, allocated on first use */
+    /* staging of pt_film_read / pt_films_reduce, made on first use and kept: the split {rgb, passes}
+     * copy of the film that goes to the host, and (root film of a reduce) the summed film */
+    float* d_read_rgb = nullptr;
+    int32_t* d_read_passes = nullptr;
+    float4* d_reduce_sum = nullptr;
 };
+
+static int film_ensure_read_staging(pt_film* f) {
+    const size_t n = (size_t)f->width * f->height;
+    if (!f->d_read_rgb) HIP_TRY(hipMalloc((void**)&f->d_read_rgb, n * 12));
+    if (!f->d_read_passes) HIP_TRY(hipMalloc((void**)&f->d_read_passes, n * 4));
+    return PT_OK;
+}
 
 static size_t batch_paths_limit() {
     const char* e = getenv("PT_BATCH_PATHS");
@@ -1707,6 +1718,9 @@ void pt_film_destroy(pt_film* f) {
     (void)hipStreamSynchronize(f->scene->stream);
     if (f->scene->stream2) (void)hipStreamSynchronize(f->scene->stream2);
     film_free_scratch(f);
+    if (f->d_read_rgb) (void)hipFree(f->d_read_rgb);
+    if (f->d_read_passes) (void)hipFree(f->d_read_passes);
+    if (f->d_reduce_sum) (void)hipFree(f->d_reduce_sum);
     if (f->owns && f->d_film) (void)hipFree(f->d_film);
     delete f;
 }
@@ -1727,13 +1741,12 @@ int pt_film_read(pt_film* f, float* rgb_sum, int32_t* passes) {
     int rc = set_device(s);
     if (rc) return rc;
     size_t n = (size_t)f->width * f->height;
-    DevBuf d_rgb, d_p;
-    rc = d_rgb.alloc(n * 12); if (rc) return rc;
-    rc = d_p.alloc(n * 4); if (rc) return rc;
-    hipLaunchKernelGGL(k_film_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, f->d_film, n, (float*)d_rgb.p, (int32_t*)d_p.p);
+    rc = film_ensure_read_staging(f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_film_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, f->d_film, n, f->d_read_rgb, f->d_read_passes);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(rgb_sum, d_rgb.p, n * 12, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(passes, d_p.p, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(rgb_sum, f->d_read_rgb, n * 12, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(passes, f->d_read_passes, n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PT_OK;
 }
@@ -1751,6 +1764,7 @@ struct RcclApi {
     std::vector<ncclComm_t> comms;
 };
 static RcclApi g_rccl;
+static std::mutex g_rccl_mu;   /* pt_films_reduce holds it from loading the library to the end of the collective */
 
 static int rccl_load() {
     if (g_rccl.lib) return PT_OK;
@@ -1790,6 +1804,8 @@ int pt_films_reduce(pt_film* const* films, int n, float* rgb_sum, int32_t* passe
     }
     const char* force = getenv("PT_FILMS_REDUCE");   /* "rccl": use the collective even for one film */
     if (n == 1 && !(force && strcmp(force, "rccl") == 0)) return pt_film_read(films[0], rgb_sum, passes);
+    /* the loaded library and the cached communicators are process-wide: one reduce at a time */
+    std::lock_guard<std::mutex> guard(g_rccl_mu);
     int rc = rccl_load();
     if (rc) return rc;
     std::vector<int> devs((size_t)n);
@@ -1805,27 +1821,42 @@ int pt_films_reduce(pt_film* const* films, int n, float* rgb_sum, int32_t* passe
     const size_t npx = (size_t)root->width * root->height;
     rc = set_device(root->scene);
     if (rc) return rc;
-    DevBuf d_sum, d_rgb, d_p;
-    rc = d_sum.alloc(npx * 16); if (rc) return rc;
-    rc = d_rgb.alloc(npx * 12); if (rc) return rc;
-    rc = d_p.alloc(npx * 4); if (rc) return rc;
-    /* every film's stream is ordered after its rendering, so the reduce reads finished films */
+    /* the root film keeps the summed film and the split copy from call to call */
+    rc = film_ensure_read_staging(root);
+    if (rc) return rc;
+    if (!root->d_reduce_sum) HIP_TRY(hipMalloc((void**)&root->d_reduce_sum, npx * 16));
+    /* Every film's stream is ordered after its rendering, so the reduce reads finished films.
+     * Whatever fails between GroupStart and GroupEnd, the group is closed before returning: an
+     * open group would swallow the next collective of this thread. */
     RCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < n; i++) {
-        HIP_TRY(hipSetDevice(films[i]->scene->device));
-        RCCL_TRY(g_rccl.Reduce(films[i]->d_film, i == 0 ? d_sum.p : (void*)films[i]->d_film, npx * 4, ncclFloat, ncclSum, 0,
-                               g_rccl.comms[(size_t)i], films[i]->scene->stream));
+    std::string group_error;
+    for (int i = 0; i < n && group_error.empty(); i++) {
+        hipError_t he = hipSetDevice(films[i]->scene->device);
+        if (he != hipSuccess) { group_error = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+        ncclResult_t nr = g_rccl.Reduce(films[i]->d_film, i == 0 ? (void*)root->d_reduce_sum : (void*)films[i]->d_film, npx * 4, ncclFloat,
+                                        ncclSum, 0, g_rccl.comms[(size_t)i], films[i]->scene->stream);
+        if (nr != ncclSuccess) group_error = std::string("ncclReduce: ") + g_rccl.GetErrorString(nr);
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    {
+        ncclResult_t nr = g_rccl.GroupEnd();
+        if (nr != ncclSuccess && group_error.empty()) group_error = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(nr);
+    }
+    if (!group_error.empty()) {
+        /* the communicators may be left in an error state: make the next call build new ones */
+        for (ncclComm_t c : g_rccl.comms) if (c) (void)g_rccl.CommDestroy(c);
+        g_rccl.comms.clear(); g_rccl.devices.clear();
+        (void)hipSetDevice(root->scene->device);
+        return fail(PT_ERR_DEVICE, group_error);
+    }
     for (int i = n - 1; i >= 0; i--) {
         HIP_TRY(hipSetDevice(films[i]->scene->device));
         HIP_TRY(hipStreamSynchronize(films[i]->scene->stream));
     }
     pt_scene* s = root->scene;   /* the current device is the root's again */
-    hipLaunchKernelGGL(k_film_split, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s->stream, (const float4*)d_sum.p, npx, (float*)d_rgb.p, (int32_t*)d_p.p);
+    hipLaunchKernelGGL(k_film_split, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s->stream, (const float4*)root->d_reduce_sum, npx, root->d_read_rgb, root->d_read_passes);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(rgb_sum, d_rgb.p, npx * 12, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(passes, d_p.p, npx * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(rgb_sum, root->d_read_rgb, npx * 12, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(passes, root->d_read_passes, npx * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return PT_OK;
 }
@@ -2038,21 +2069,27 @@ int pt_cast_rays(pt_scene* s, const pt_camera* cam, const pt_light* lights, int 
     int rc = set_device(s);
     if (rc) return rc;
     /* scratch that lives for the call */
-    struct Scratch { RenderLane ln; uint32_t* d_ids = nullptr; ~Scratch() { lane_free_scratch(&ln); if (ln.h_cnt) (void)hipHostFree(ln.h_cnt); if (ln.film_done) (void)hipEventDestroy(ln.film_done); if (d_ids) (void)hipFree(d_ids); } } sc;
+    /* (its destructor waits for the stream first: on an early return copies and kernels that use these
+     * buffers, and the host arrays below, may still be queued) */
+    struct Scratch { RenderLane ln; uint32_t* d_ids = nullptr; hipStream_t st = nullptr; ~Scratch() { if (st) (void)hipStreamSynchronize(st); lane_free_scratch(&ln); if (ln.h_cnt) (void)hipHostFree(ln.h_cnt); if (ln.film_done) (void)hipEventDestroy(ln.film_done); if (d_ids) (void)hipFree(d_ids); } };
+    /* host staging declared before `sc`, so that it outlives the wait in sc's destructor */
+    std::vector<float> r((size_t)n), g((size_t)n), bl((size_t)n);
+    DLight hl[PT_MAX_LIGHTS];
+    const uint32_t n32 = (uint32_t)n;
+    Scratch sc;
+    sc.st = s->stream;
     rc = lane_ensure_scratch(&sc.ln, (size_t)n, (uint32_t)n_lights, 1);
     if (rc) return rc;
     RenderBuffers& b = sc.ln.rb;
     hipStream_t st = s->stream;
     CamParams cp;
     fill_cam(cp, cam, 1, 1);   /* only sky colour and the two modes are used past the camera rays */
-    DLight hl[PT_MAX_LIGHTS];
     for (int l = 0; l < n_lights; l++) {
         hl[l].pos = v3(lights[l].position[0], lights[l].position[1], lights[l].position[2]);
         hl[l].color = v3(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
     }
     if (n_lights > 0) HIP_TRY(hipMemcpyAsync(sc.ln.d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, st));
-    const uint32_t n32 = (uint32_t)n;
     HIP_TRY(hipMemcpyAsync(b.cnt + CNT_QUEUE, &n32, 4, hipMemcpyHostToDevice, st));
     const float* src[6] = {ox, oy, oz, dx, dy, dz};
     float* dst[6] = {b.q[0].ox, b.q[0].oy, b.q[0].oz, b.q[0].dx, b.q[0].dy, b.q[0].dz};
@@ -2066,7 +2103,6 @@ int pt_cast_rays(pt_scene* s, const pt_camera* cam, const pt_light* lights, int 
     const LaunchCtx ctx{st, s->d_spill};
     rc = enqueue_bounces(s, b, ctx, cp, sc.ln.d_lights, (uint32_t)n_lights, (uint32_t)recursions, seed);
     if (rc) return rc;
-    std::vector<float> r((size_t)n), g((size_t)n), bl((size_t)n);
     HIP_TRY(hipMemcpyAsync(r.data(), b.rad_r, n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(g.data(), b.rad_g, n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(bl.data(), b.rad_b, n * 4, hipMemcpyDeviceToHost, st));

@@ -456,10 +456,10 @@ RenderThread::~RenderThread() {
     delete integrator;
 }
 
-void RenderThread::send_message(RenderMessage message) {
-    if (!parent->hold_queue) pthread_mutex_lock(&parent->messages_lock); /* else the issuing thread already holds it */
+void RenderThread::send_message(RenderMessage message, bool queue_locked) {
+    if (!queue_locked) pthread_mutex_lock(&parent->messages_lock); /* else this very thread holds it */
     parent->messages.push_back(message);
-    if (!parent->hold_queue) pthread_mutex_unlock(&parent->messages_lock);
+    if (!queue_locked) pthread_mutex_unlock(&parent->messages_lock);
     sem_post(&parent->messages_semaphore);
 }
 
@@ -599,7 +599,6 @@ RenderEngine::RenderEngine(int _width, int _height, Scene* _scene) : width(_widt
     semaphore_passes_pending = 0;
     sample_base = 0;
     render_errors = 0;
-    hold_queue = false;
     next_global_sample = 0;
     mixed_rectangles = false;
     int n = get_optimal_thread_count();
@@ -628,7 +627,7 @@ RenderEngine::~RenderEngine() {
 
 void RenderEngine::issue_pass_desc(PassDescriptor desc) { issue_pass_run(desc, 1); }
 
-void RenderEngine::issue_pass_run(PassDescriptor desc, int count) {
+void RenderEngine::issue_pass_run(PassDescriptor desc, int count, bool queue_locked) {
     if (workers.empty() || count <= 0) return;
     PassDescriptor key = desc;
     key.clamp_bounds(width, height);
@@ -662,7 +661,7 @@ void RenderEngine::issue_pass_run(PassDescriptor desc, int count) {
     pthread_mutex_lock(&master_lock);
     total_passes_issued += count;
     pthread_mutex_unlock(&master_lock);
-    workers[(size_t)worker]->send_message(RenderMessage({false, desc, sample, (uint32_t)count}));
+    workers[(size_t)worker]->send_message(RenderMessage({false, desc, sample, (uint32_t)count}), queue_locked);
     semaphore_passes_pending++;
 }
 
@@ -692,11 +691,9 @@ void RenderEngine::perform_full_passes(int pass_count) { /* integrator.cpp:428-4
     stable_sort(tile_spots.begin(), tile_spots.end(), tile_compare);
     /* the queue is held while the runs go in, so that the first worker to wake sees all of them and
      * sizes its first batch by the whole job instead of by the few entries queued so far */
-    hold_queue = true;
     pthread_mutex_lock(&messages_lock);
-    for (auto spot : tile_spots) issue_pass_run(PassDescriptor(spot.first, spot.second, tile_width, tile_height), pass_count);
+    for (auto spot : tile_spots) issue_pass_run(PassDescriptor(spot.first, spot.second, tile_width, tile_height), pass_count, true);
     pthread_mutex_unlock(&messages_lock);
-    hold_queue = false;
 }
 
 /* Waits until every pass issued so far has been rendered.  Completion is counted in passes, under
@@ -746,6 +743,12 @@ int RenderEngine::rebuild_master_canvas() {
             if (workers[a]->integrator->device == workers[b]->integrator->device) one_film_per_gpu = false;
     const bool want_rccl = how ? forced_rccl : (workers.size() > 1 && one_film_per_gpu);
     last_reduce_how = "host";
+    if (forced_rccl && !one_film_per_gpu) {
+        /* refused before any lock is taken: the collective sums one film per GPU */
+        last_error = "device-side film reduce failed: one film per GPU required (several workers share a GPU)";
+        cerr << "rebuild_master_canvas: " << last_error << endl;
+        return -1;
+    }
     if (want_rccl && !workers.empty()) {
         vector<pt_film*> films;
         for (auto worker : workers) {
@@ -757,10 +760,15 @@ int RenderEngine::rebuild_master_canvas() {
         string why = "a worker has no film";
         if (films.size() == workers.size()) {
             vector<float> rgb((size_t)master_canvas->size * 3);
-            for (auto worker : workers) scene->tree->lock_device(worker->integrator->device);
+            /* every distinct GPU once, in ascending order (the per-GPU locks are not recursive) */
+            vector<int> devices;
+            for (auto worker : workers) devices.push_back(worker->integrator->device);
+            sort(devices.begin(), devices.end());
+            devices.erase(unique(devices.begin(), devices.end()), devices.end());
+            for (int d : devices) scene->tree->lock_device(d);
             rc = pt_films_reduce(films.data(), (int)films.size(), rgb.data(), master_canvas->per_pixel_passes);
             if (rc != PT_OK) why = pt_last_error();
-            for (auto worker : workers) scene->tree->unlock_device(worker->integrator->device);
+            for (size_t k = devices.size(); k-- > 0;) scene->tree->unlock_device(devices[k]);
             if (rc == PT_OK)
                 for (int i = 0; i < master_canvas->size; i++)
                     master_canvas->pixels[i] = Vec(rgb[3 * (size_t)i], rgb[3 * (size_t)i + 1], rgb[3 * (size_t)i + 2]);

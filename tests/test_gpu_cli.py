@@ -176,3 +176,17 @@ def test_two_workers_share_the_queue(tmp_path, scene_small):
     want = orc.tonemap(rgb, passes).reshape(H, W, 3)
     diff = np.abs(outs["2"].astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+
+
+def test_forced_collective_with_shared_gpu_is_refused(tmp_path, scene_small):
+    """Two workers on ONE GPU and the RCCL reduce asked for by name: the collective sums one film per
+    GPU, so rebuild_master_canvas must refuse cleanly (non-zero exit, reason on stderr) -- not hang
+    on the GPU's lock, not substitute the host sum."""
+    stl = str(tmp_path / "standin.stl")
+    pta.meshgen.write_stl(stl, scene_small.tris)
+    out = str(tmp_path / "refused.png")
+    cmd = [CLI, stl, "--output", out, "--width", "160", "--height", "96", "--samples", "2", "--seed", "2"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, PT_ENGINE_WORKERS="2", PT_FILMS_REDUCE="rccl"))
+    assert res.returncode != 0, res.stdout + res.stderr
+    assert "one film per GPU required" in res.stderr, res.stderr
