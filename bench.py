@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 # the L2's aggregate bandwidth is 34.5 TB/s).  This repository's own micro-benchmark of the exact
 # access shape (64 lanes each loading their own 64-byte record) gets 13.4 TB/s.
 L2_GATHER_PEAK_GBS = 16800.0
+L2_AGGREGATE_GBS = 34500.0
 OWN_GATHER_RATE_GBS = 13400.0
 INFINITY_CACHE_BYTES = 256 << 20
 
@@ -59,6 +60,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--lambertian", action="store_true",
+                    help="the flagged Lambertian bounce mode (reference integrator.cpp:79-84 without :104) instead of mirror bounces")
     ap.add_argument("--rehearse", action="store_true",
                     help="run the N-rank code path on ONE GPU: gloo backend, every rank on device 0, films reduced through host copies")
     return ap.parse_args()
@@ -125,11 +128,11 @@ def launch_ranks(n_ranks):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    if status == 0:
-        sys.stdout.write(line0.decode())
-        sys.stdout.flush()
-    else:
-        sys.stderr.write(line0.decode())
+    # only the JSON line goes to stdout; whatever else rank 0 or its libraries printed there goes to stderr
+    for text in line0.decode(errors="replace").splitlines():
+        is_result = text.startswith("{") and status == 0
+        print(text, file=sys.stdout if is_result else sys.stderr, flush=True)
+    if status != 0:
         print("[bench] a rank exited with status %d" % status, file=sys.stderr)
     return status
 
@@ -181,7 +184,7 @@ def main():
     film_t = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     film = pta.Film(gpu, W, H, external=film_t)
-    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5, bounce_mode=1 if args.lambertian else 0)
     lights = pta.cli_lights()
 
     def reduce_to_rank0():
@@ -300,7 +303,7 @@ def main():
         rays_ref = closest_all + shadow_all
         rays_traced = closest_all + traced_all
         value = rays_traced / elapsed / 1e6
-        std_cfg = (args.level, W, H) == (8, 1920, 1080)
+        std_cfg = (args.level, W, H) == (8, 1920, 1080) and not args.lambertian
         per_step = ("%d spp per step split over the ranks" % args.total_spp) if strong else ("%d spp per step per GPU" % spp)
         out = {
             "metric": "Mrays/s (all bounces)", "value": round(value, 2), "unit": "Mrays/s",
@@ -311,11 +314,14 @@ def main():
             "config": {
                 "workload": "full path trace (" + ("configs[2]" if std_cfg else "other scene or size") +
                             "): stand-in bumpy icosphere level %d + floor, %d triangles, "
-                            "3 lights, mirror bounces <= 10, DOF 0.1/4.5, %dx%d, %s"
-                            % (args.level, host.n, W, H, per_step),
+                            "3 lights, %s <= 10, DOF 0.1/4.5, %dx%d, %s"
+                            % (args.level, host.n, "LAMBERTIAN bounces (flagged extension: integrator.cpp:79-84 without :104)"
+                               if args.lambertian else "mirror bounces", W, H, per_step),
                 "triangles": host.n, "width": W, "height": H, "spp_per_step": args.total_spp if strong else spp,
                 "parallelism": "sample-partitioned x%d, one %s reduce of the film" % (world, "gloo (rehearsal on one GPU)" if args.rehearse else "RCCL"),
             },
+            "value_definition": "rays traced per second of wall time: closest-hit casts + shadow casts of light samples with "
+                                "non-zero weight; reference_counted_Mrays_per_s is the other definition (every cast the reference makes)",
             "ray_counting": "value = rays traced per second (closest-hit casts + shadow rays of light samples with non-zero weight); "
                             "reference_counted_Mrays_per_s also counts the shadow rays of zero-weight light samples, which the "
                             "reference casts and this renderer counts but does not trace (same picture bit for bit)",
@@ -336,6 +342,7 @@ def main():
         roof = None
         cpu = None
         if not args.no_cpu_baseline:
+            import ctypes as C
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc
             threads = args.cpu_threads or host_threads(1)
@@ -343,25 +350,39 @@ def main():
             oscene = orc.Scene(tris, threads=threads)
             t_oracle_build = time.time() - tb
             note("oracle scene in %.1f s" % t_oracle_build)
-            ocam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5)
-            # work per ray in the reference's visit order: every 4th 8-row band of the frame, 1 spp
-            bands = [(0, y, W, min(8, H - y)) for y in range(0, H, 32)]
-            work = np.zeros(6, dtype=np.uint64)
+            ocam = orc.cli_camera(dof_aperture=0.1, dof_distance=4.5, bounce_mode=cam.bounce_mode)
+            # Work per ray on a sample of the frame (every 8th 8-row band, 1 spp):
+            #  - box and triangle tests of the reference's visit order (the oracle's counting walk), and
+            #  - the records the device walks fetch: the rays the oracle casts on the sample, replayed
+            #    through the kernels' own lane logic (csrc/traverse_core.h compiled for the CPU,
+            #    tests/native/traverse_emul.cpp) with a counter on every record load.
+            emul = C.CDLL(os.path.join(ROOT, "tests", "native", "_build", "libtraverse_emul.so"))
+            emul.emul_work_counts.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+            bands = [(0, y, W, min(8, H - y)) for y in range(0, H, 64)]
+            work = np.zeros(7, dtype=np.uint64)
+            fetched = np.zeros(12, dtype=np.uint64)
             rgb = np.zeros((H, W, 3), np.float32)
             pas = np.zeros((H, W), np.int32)
+            flat = host.flat
             for b in bands:
                 _, _, c = oscene.render(ocam, orc.cli_lights(), W, H, b, 0, 1, seed=args.seed, threads=threads,
                                         rgb=rgb, passes=pas, count_work=True)
                 work += c
+                rays8 = oscene.render_capture(ocam, orc.cli_lights(), W, H, b, 0, 1, seed=args.seed)
+                emul.emul_work_counts(C.byref(flat), rays8.shape[0], rays8.ctypes.data_as(C.c_void_p), fetched.ctypes.data_as(C.c_void_p))
+            note("work counts on %d sample bands done" % len(bands))
             n_box_c, n_tri_c = work[2] / work[0], work[3] / work[0]
-            n_box_s, n_tri_s = work[4] / max(work[1], 1), work[5] / max(work[1], 1)
             b_closest = n_box_c * 32 + n_tri_c * 36 + 24 + 16
-            b_shadow = n_box_s * 32 + n_tri_s * 36 + 24 + 1
+            assert int(fetched[0]) == int(work[0]) and int(fetched[4] + fetched[8]) == int(work[6])
+            # records per ray the device walks fetch (64-byte node records, 48-byte triangle records)
+            nodes_c, tris_c = fetched[1] / fetched[0], fetched[2] / fetched[0]
+            n_sh = max(int(fetched[4] + fetched[8]), 1)
+            nodes_s, tris_s = (fetched[5] + fetched[9]) / n_sh, (fetched[6] + fetched[10]) / n_sh
             if world == 1:
                 # CPU baseline: whole passes of the same frame until about 20 s of CPU time are spent
                 rgb[:] = 0
                 pas[:] = 0
-                cnt = np.zeros(2, dtype=np.uint64)
+                cnt = np.zeros(3, dtype=np.uint64)
                 n_pass = 0
                 tb = time.time()
                 rows = H
@@ -374,81 +395,98 @@ def main():
                     if t_cpu * threads >= 20.0 or n_pass >= 64:
                         break
                 n_samp = int(pas.sum())
-                cpu = {"value": round(float(cnt.sum()) / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+                cpu = {"value": round(float(cnt[0] + cnt[2]) / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": threads,
                        "kind": "port",
+                       "value_definition": "the same rays as `value` counts (closest-hit casts + shadow casts of light samples "
+                                           "with non-zero weight) per second; the CPU code casts the zero-weight ones too, "
+                                           "see reference_counted_Mrays_per_s",
+                       "reference_counted_Mrays_per_s": round(float(cnt[0] + cnt[1]) / t_cpu / 1e6, 3),
                        "sample": "CPU oracle (strict-IEEE restatement of the reference path), %d threads, %d full "
-                                 "%dx%d passes = %d camera samples in %.2f s; extrapolates to %.0f s per 1000 spp; rays "
-                                 "counted as the reference casts them"
+                                 "%dx%d passes = %d camera samples in %.2f s; extrapolates to %.0f s per 1000 spp"
                                  % (threads, n_pass, W, H, n_samp, t_cpu, t_cpu / n_samp * W * H * 1000),
                        "camera_samples_per_s": round(n_samp / t_cpu, 1),
                        "oracle_scene_build_s": round(t_oracle_build, 2)}
-            ms_c, launches_c = kt[0]
-            if ms_c > 0 and launches_c > 0:
-                closest = tally.closest                       # rank 0's own launches
-                rays_per_launch = closest / launches_c
-                launch_s = ms_c / launches_c * 1e-3
-                algorithmic = rays_per_launch * b_closest / launch_s / 1e9
-                # what the kernel loads into registers: one 64-byte record per node visit (two box tests),
-                # 48 bytes per triangle test, the ray; plus the 16-byte hit it stores
-                loaded_per_ray = n_box_c * 32 + n_tri_c * 48 + 24 + 16
+            scene_bytes = host.flat.n_nodes * 64 + host.n * (48 + 64)
+            key = "level%d_%dx%d" % (args.level, W, H) + ("_lambert" if args.lambertian else "")
+            tr = measured_traffic(key)
+
+            def price(name, cls, rays, nodes_per_ray, tris_per_ray, io_bytes, algorithmic_bytes):
+                """Roofline entry of one trace-kernel class from this run's event times."""
+                ms, launches = kt[cls]
+                if not (ms > 0 and launches > 0 and rays > 0):
+                    return None
+                rays_per_launch = rays / launches
+                launch_s = ms / launches * 1e-3
+                loaded_per_ray = nodes_per_ray * 64 + tris_per_ray * 48 + io_bytes
                 loaded = rays_per_launch * loaded_per_ray / launch_s / 1e9
-                scene_bytes = host.flat.n_nodes * 64 + host.n * (48 + 64)
-                key = "level%d_%dx%d" % (args.level, W, H)
-                tr = measured_traffic(key)
-                traffic = round(tr["closest_bytes_per_ray"] * rays_per_launch, 1) if tr else None
-                hbm_meas = None
-                if tr:
-                    g = tr["closest_bytes_per_ray"] * rays_per_launch / launch_s / 1e9
-                    hbm_meas = {"GBps": round(g, 1), "frac_of_hbm_peak": round(g / HBM_PEAK_GBS, 4),
-                                "bytes_per_ray": round(tr["closest_bytes_per_ray"], 1),
-                                "l2_hit_rate": round(tr.get("closest_l2_hit_rate", float("nan")), 4),
-                                "source": "profiles/traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                          "2*FETCH_SIZE + WRITE_SIZE) x this run's rays per second in the kernel" % key}
-                if scene_bytes > INFINITY_CACHE_BYTES and algorithmic <= HBM_PEAK_GBS:
-                    # the scene streams from HBM: the algorithmic bytes are priced against the HBM peak
-                    # (should the caches ever serve so much of them that this exceeds the peak, it stops
-                    # being a roofline and the load path below is quoted instead)
-                    roof = {"bound": "hbm", "achieved": round(algorithmic, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(algorithmic / HBM_PEAK_GBS, 5), "traffic": traffic}
+                e = {"kernel": name, "share_of_kernel_ms": round(ms / sum(v[0] for v in kt.values()), 4),
+                     "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(ms / launches, 4),
+                     "node_records_per_ray": round(float(nodes_per_ray), 3), "tri_records_per_ray": round(float(tris_per_ray), 3),
+                     "loaded_bytes_per_ray": round(float(loaded_per_ray), 1), "loaded_GBps": round(loaded, 2),
+                     "frac_of_l2_gather_rate": round(loaded / L2_GATHER_PEAK_GBS, 5),
+                     "frac_of_l2_aggregate": round(loaded / L2_AGGREGATE_GBS, 5),
+                     "frac_of_own_microbenchmark": round(loaded / OWN_GATHER_RATE_GBS, 4)}
+                if algorithmic_bytes is not None:
+                    alg = rays_per_launch * algorithmic_bytes / launch_s / 1e9
+                    e.update({"algorithmic_bytes_per_ray": round(float(algorithmic_bytes), 1), "algorithmic_GBps": round(alg, 2),
+                              "algorithmic_over_hbm_peak": round(alg / HBM_PEAK_GBS, 4)})
+                pre = "closest" if cls == 0 else "shadow"
+                if tr and pre + "_bytes_per_ray" in tr:
+                    g = tr[pre + "_bytes_per_ray"] * rays_per_launch / launch_s / 1e9
+                    e["traffic"] = round(tr[pre + "_bytes_per_ray"] * rays_per_launch, 1)
+                    e["hbm_measured"] = {"GBps": round(g, 1), "frac_of_hbm_peak": round(g / HBM_PEAK_GBS, 4),
+                                         "bytes_per_ray": round(tr[pre + "_bytes_per_ray"], 1),
+                                         "l2_hit_rate": round(tr.get(pre + "_l2_hit_rate", float("nan")), 4),
+                                         "source": "profiles/traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                   "command, 2*FETCH_SIZE + WRITE_SIZE) x this run's rays per second in the kernel" % key}
+                    if pre + "_valu_issue_utilisation" in tr:
+                        e["valu_measured"] = {"issue_utilisation": round(tr[pre + "_valu_issue_utilisation"], 4),
+                                              "lane_utilisation": round(tr[pre + "_valu_lane_utilisation"], 4),
+                                              "instructions_per_64_rays": round(tr[pre + "_valu_instructions_per_64_rays"], 1)}
                 else:
-                    # the scene (nodes + triangle records) sits in L2 / Infinity Cache: the ceiling that binds is
-                    # the compute units' L2 gather path, priced with the bytes the kernel really loads
-                    roof = {"bound": "l2", "achieved": round(loaded, 2), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(loaded / L2_GATHER_PEAK_GBS, 5), "traffic": traffic,
+                    e["traffic"] = None
+                return e
+
+            # closest-hit: per ray the 24-byte ray in and the 16-byte hit out; any-hit: the ray, its light distance and
+            # target entry in (32 bytes), one visibility byte out
+            pc = price("k_trace<closest>", 0, tally.closest, nodes_c, tris_c, 24 + 16, b_closest)
+            ps = price("k_trace<shadow>", 1, tally.traced, nodes_s, tris_s, 32 + 1, None)
+            entries = [e for e in (pc, ps) if e]
+            if entries:
+                dom = max(entries, key=lambda e: e["share_of_kernel_ms"])
+                other = [e for e in entries if e is not dom]
+                streams_from_hbm = scene_bytes > INFINITY_CACHE_BYTES and dom.get("algorithmic_GBps") is not None \
+                    and dom["algorithmic_GBps"] <= HBM_PEAK_GBS
+                if streams_from_hbm:
+                    # the scene streams from HBM: the algorithmic bytes are priced against the HBM peak
+                    roof = {"bound": "hbm", "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(dom["algorithmic_GBps"] / HBM_PEAK_GBS, 5)}
+                else:
+                    # The scene (nodes + triangle records) is served by L2 / Infinity Cache: what binds is the compute
+                    # units' gather path, priced with the bytes the kernel really loads.  The ceiling quoted is the
+                    # hardware guide's MEASURED rate for gathers of L2-resident rows (16.8 TB/s), not a peak; the
+                    # fraction of the L2's aggregate bandwidth (34.5 TB/s) is given beside it.
+                    roof = {"bound": "l2", "achieved": dom["loaded_GBps"], "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(dom["loaded_GBps"] / L2_GATHER_PEAK_GBS, 5),
+                            "peak_is": "a measured gather rate (hardware guide: 16.8-18.8 TB/s for L2-resident row gathers), not a "
+                                       "hardware peak; frac_of_l2_aggregate prices the same bytes against the L2's 34.5 TB/s",
                             "peak_sources": {"hardware_guide_l2_resident_row_gather_GBps": [16800.0, 18800.0],
-                                             "hardware_guide_l2_aggregate_GBps": 34500.0,
+                                             "hardware_guide_l2_aggregate_GBps": L2_AGGREGATE_GBS,
                                              "own_microbenchmark_64B_per_lane_records_GBps": OWN_GATHER_RATE_GBS,
-                                             "own_microbenchmark_source": "scripts/micro/gather_rate.hip, profiles/r01i_micro_gather_rate.txt"},
-                            "frac_of_own_microbenchmark": round(loaded / OWN_GATHER_RATE_GBS, 4)}
-                roof.update({
-                    "kernel": "k_trace<closest>",
-                    "scene_bytes": int(scene_bytes),
-                    "loaded_bytes_per_ray": round(float(loaded_per_ray), 1),
-                    "loaded_GBps": round(loaded, 2),
-                    "algorithmic_bytes_per_ray": round(float(b_closest), 1),
-                    "algorithmic_GBps": round(algorithmic, 2),
-                    "algorithmic_over_hbm_peak": round(algorithmic / HBM_PEAK_GBS, 4),
-                    "algorithmic_note": "every box and triangle test of the reference's visit order priced at its record's bytes; "
-                                        "it exceeds what reaches HBM when the scene is cache-resident (see hbm_measured), so it is a "
-                                        "ratio, not a fraction of a roofline",
-                    "hbm_measured": hbm_meas,
-                    # from the same PMC passes (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, GRBM_GUI_ACTIVE): how busy the
-                    # SIMDs' vector issue is (a wave64 instruction = 2 cycles of a SIMD-32) and how many lanes work
-                    "valu_measured": ({"issue_utilisation": round(tr["closest_valu_issue_utilisation"], 4),
-                                       "lane_utilisation": round(tr["closest_valu_lane_utilisation"], 4),
-                                       "instructions_per_64_rays": round(tr["closest_valu_instructions_per_64_rays"], 1)}
-                                      if tr and "closest_valu_issue_utilisation" in tr else None),
-                    "box_tests_per_ray": round(float(n_box_c), 3), "tri_tests_per_ray": round(float(n_tri_c), 3),
-                    "rays_per_launch": round(rays_per_launch, 1),
-                    "avg_launch_ms": round(ms_c / launches_c, 4),
-                    "shadow_kernel": {"algorithmic_bytes_per_ray": round(float(b_shadow), 1),
-                                      "box_tests_per_ray": round(float(n_box_s), 3),
-                                      "tri_tests_per_ray": round(float(n_tri_s), 3),
-                                      "rays_traced": int(tally.traced),
-                                      "algorithmic_GBps": round(tally.traced / max(kt[1][1], 1) * b_shadow /
-                                                                (kt[1][0] / max(kt[1][1], 1) * 1e-3) / 1e9, 2) if kt[1][0] > 0 else None,
-                                      "hbm_measured_bytes_per_ray": round(tr["shadow_bytes_per_ray"], 1) if tr and "shadow_bytes_per_ray" in tr else None,
-                                      "l2_hit_rate": round(tr["shadow_l2_hit_rate"], 4) if tr and "shadow_l2_hit_rate" in tr else None}})
+                                             "own_microbenchmark_source": "scripts/micro/gather_rate.hip, profiles/r01i_micro_gather_rate.txt"}}
+                roof["traffic"] = dom.get("traffic")
+                roof["scene_bytes"] = int(scene_bytes)
+                roof["work_sample"] = "%d bands of 8 rows, 1 spp: %d closest-hit and %d traced shadow rays replayed through the lane logic" \
+                    % (len(bands), int(fetched[0]), n_sh)
+                roof["reference_order_tests_per_ray"] = {"closest_box": round(float(n_box_c), 3), "closest_tri": round(float(n_tri_c), 3),
+                                                         "shadow_box": round(float(work[4] / max(work[1], 1)), 3),
+                                                         "shadow_tri": round(float(work[5] / max(work[1], 1)), 3)}
+                roof["algorithmic_note"] = ("algorithmic bytes = every box and triangle test of the reference's visit order priced at its "
+                                            "record's bytes (closest-hit only: the any-hit walk stops at the first hit, so the reference's "
+                                            "counts are not its work); above what reaches HBM when the scene is cache-resident, so a ratio, "
+                                            "not a fraction of a roofline")
+                roof.update({k: v for k, v in dom.items() if k != "traffic"})
+                roof["other_trace_kernel"] = other[0] if other else None
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

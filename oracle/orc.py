@@ -64,6 +64,8 @@ def lib():
         L.orc_camera_rays.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, u32, u64, vp, vp]
         L.orc_render.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, u32, u32, u64, vp, vp, vp, i32]
         L.orc_render_counting.argtypes = L.orc_render.argtypes
+        L.orc_render_capture.restype = i64
+        L.orc_render_capture.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, u32, u32, u64, vp, i64]
         L.orc_cast_rays.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp, u32, i32, u64, vp, vp]
         L.orc_tonemap.argtypes = [vp, vp, i64, C.c_float, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
@@ -189,21 +191,33 @@ class Scene:
 
     def render(self, cam, lights, width, height, rect=None, first_sample=0, n_samples=1, seed=1, threads=8,
                rgb=None, passes=None, count_work=False):
-        """Returns (rgb_sum, passes, counts).  counts = [closest casts, shadow casts] or, with
-        count_work, additionally [closest box tests, closest triangle tests, shadow box tests,
-        shadow triangle tests]."""
+        """Returns (rgb_sum, passes, counts).  counts = [closest casts, shadow casts, shadow casts of
+        light samples with non-zero weight] or, with count_work, [closest casts, shadow casts, closest
+        box tests, closest triangle tests, shadow box tests, shadow triangle tests, shadow casts of
+        light samples with non-zero weight]."""
         x0, y0, w, h = rect if rect is not None else (0, 0, -1, -1)
         if rgb is None:
             rgb = np.zeros((height, width, 3), dtype=np.float32)
         if passes is None:
             passes = np.zeros((height, width), dtype=np.int32)
-        counts = np.zeros(6 if count_work else 2, dtype=np.uint64)
+        counts = np.zeros(7 if count_work else 3, dtype=np.uint64)
         larr = make_lights(lights)
         fn = lib().orc_render_counting if count_work else lib().orc_render
         fn(self.h, C.byref(cam), larr, len(lights), width, height, x0, y0, w, h, first_sample,
                          n_samples, seed, _p(rgb), _p(passes), _p(counts), threads)
         return rgb, passes, counts
 
+
+    def render_capture(self, cam, lights, width, height, rect=None, first_sample=0, n_samples=1, seed=1):
+        """Every ray the render casts, in casting order: array [n, 8] of origin, direction, light
+        distance, tag (0 closest-hit cast, 1 shadow cast with non-zero weight, 2 with zero weight)."""
+        x0, y0, w, h = rect if rect is not None else (0, 0, -1, -1)
+        larr = make_lights(lights)
+        args = (self.h, C.byref(cam), larr, len(lights), width, height, x0, y0, w, h, first_sample, n_samples, seed)
+        n = int(lib().orc_render_capture(*args, None, 0))
+        out = np.empty((n, 8), dtype=np.float32)
+        lib().orc_render_capture(*args, _p(out), n)
+        return out
 
     def cast_rays(self, cam, lights, o, d, ids=None, sample=0, recursions=10, seed=1):
         """Integrator::cast_ray for given rays: (rgb [n,3], [closest casts, shadow casts])."""

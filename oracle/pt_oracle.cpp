@@ -667,7 +667,21 @@ struct PathCtx {
     uint64_t closest_casts, shadow_casts;
     Counters* work_closest; /* optional: box/triangle tests spent on closest-hit casts */
     Counters* work_shadow;  /* ... and on shadow casts */
+    /* Bookkeeping for the GPU renderer's own ray accounting (not part of the reference): a light
+     * sample whose weight is exactly zero for all three colours adds nothing whether its light is
+     * visible or not; the GPU renderer counts such a shadow ray but does not trace it.
+     * shadow_weighted counts the others; capture (optional) receives every ray cast, 8 floats each:
+     * origin, direction, light distance (0 for closest-hit casts), and a tag (0 closest-hit cast,
+     * 1 shadow cast with a non-zero weight, 2 shadow cast with zero weight). */
+    uint64_t shadow_weighted = 0;
+    std::vector<float>* capture = nullptr;
 };
+
+inline void capture_ray(PathCtx& ctx, const Ray& r, float dist, float tag) {
+    if (!ctx.capture) return;
+    const float rec[8] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, dist, tag};
+    ctx.capture->insert(ctx.capture->end(), rec, rec + 8);
+}
 
 inline bool scene_ray_test(const Scene* s, const Ray& ray, Hit& h, Counters* cn = nullptr) {
     CastingRay c = make_casting(ray); /* kdtree.cpp:577-580: implicit Ray -> CastingRay */
@@ -679,6 +693,7 @@ inline bool scene_ray_test(const Scene* s, const Ray& ray, Hit& h, Counters* cn 
 V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
     Hit h;
     ctx.closest_casts++;
+    capture_ray(ctx, ray, 0.0f, 0.0f);
     bool result = scene_ray_test(ctx.scene, ray, h, ctx.work_closest);
     V3 energy = mk(0, 0, 0);
     if (!result) return ctx.sky; /* :153 */
@@ -719,6 +734,16 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
         Hit sh;
         ctx.shadow_casts++;
         float dist = norm(to_light);
+        {   /* the sample's weight as the GPU renderer forms it: throughput 0.8^depth (one binary32
+             * product per bounce) times colour / dist^2 * (lambert + phong^16) */
+            float thr = 1.0f;
+            for (int k = 0; k < depth; k++) thr = 0.8f * thr;
+            V3 wgt = (lc / (dist * dist)) * (real_max(0.0f, dot(n, to_light) / dist) +
+                                             square(square(square(square(real_max(0.0f, dot(reflection, to_light) / dist))))));
+            const bool zero = thr * wgt.x == 0.0f && thr * wgt.y == 0.0f && thr * wgt.z == 0.0f;
+            if (!zero) ctx.shadow_weighted++;
+            capture_ray(ctx, shadow, dist, zero ? 2.0f : 1.0f);
+        }
         bool visible;
         if (ctx.shadow_mode == 1) {
             /* flagged extension: a light is hidden only by a triangle nearer than the light */
@@ -916,7 +941,8 @@ void orc_camera_rays(const orc_camera* cam, int width, int height, int x0, int y
 
 static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
                         int height, int x0, int y0, int w, int h, uint32_t first_sample, uint32_t n_samples, uint64_t seed,
-                        float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads, bool count_work) {
+                        float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads, bool count_work,
+                        std::vector<float>* capture = nullptr) {
     if (n_lights > MAX_LIGHTS) n_lights = MAX_LIGHTS;
     /* PassDescriptor::clamp_bounds, integrator.cpp:164-183 */
     if (x0 < 0) x0 = 0;
@@ -929,7 +955,8 @@ static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_lig
     if (h > height - y0) h = height - y0;
     CameraBasis basis = camera_basis(*cam, width, height);
     int nthreads = threads < 1 ? 1 : threads;
-    std::vector<uint64_t> counts((size_t)nthreads * 6, 0);
+    if (capture) nthreads = 1;   /* rays are captured in the order one thread casts them */
+    std::vector<uint64_t> counts((size_t)nthreads * 7, 0);
     /* Rows are dealt round-robin in blocks so threads finish together. */
     std::vector<std::thread> pool;
     auto work = [&](int tid) {
@@ -942,6 +969,7 @@ static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_lig
         Counters wc, ws;
         ctx.work_closest = count_work ? &wc : nullptr;
         ctx.work_shadow = count_work ? &ws : nullptr;
+        ctx.capture = capture;
         for (int y = y0 + tid; y < y0 + h; y += nthreads)
             for (int x = x0; x < x0 + w; x++) {
                 int pix = y * width + x;
@@ -955,9 +983,10 @@ static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_lig
                     passes[pix] += 1;                         /* :265 */
                 }
             }
-        uint64_t* c = &counts[6 * (size_t)tid];
+        uint64_t* c = &counts[7 * (size_t)tid];
         c[0] = ctx.closest_casts; c[1] = ctx.shadow_casts;
         c[2] = wc.box; c[3] = wc.tri; c[4] = ws.box; c[5] = ws.tri;
+        c[6] = ctx.shadow_weighted;
     };
     if (nthreads == 1) work(0);
     else {
@@ -965,8 +994,11 @@ static void render_impl(const orc_scene* s, const orc_camera* cam, const orc_lig
         for (auto& th : pool) th.join();
     }
     if (ray_counts)
-        for (int t = 0; t < nthreads; t++)
-            for (int k = 0; k < (count_work ? 6 : 2); k++) ray_counts[k] += counts[6 * (size_t)t + k];
+        for (int t = 0; t < nthreads; t++) {
+            const uint64_t* c = &counts[7 * (size_t)t];
+            if (count_work) { for (int k = 0; k < 7; k++) ray_counts[k] += c[k]; }
+            else { ray_counts[0] += c[0]; ray_counts[1] += c[1]; ray_counts[2] += c[6]; }
+        }
 }
 
 void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
@@ -981,6 +1013,21 @@ void orc_render_counting(const orc_scene* s, const orc_camera* cam, const orc_li
                          uint64_t seed, float* rgb_sum, int32_t* passes, uint64_t* work_counts, int threads) {
     render_impl(s, cam, lights, n_lights, width, height, x0, y0, w, h, first_sample, n_samples, seed, rgb_sum, passes,
                 work_counts, threads, true);
+}
+
+/* The same render on one thread, handing back every ray it casts, in casting order: 8 floats per
+ * ray (origin, direction, light distance, tag; see PathCtx::capture).  Returns the number of rays;
+ * rays beyond `cap` are counted but not stored. */
+int64_t orc_render_capture(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int width,
+                           int height, int x0, int y0, int w, int h, uint32_t first_sample, uint32_t n_samples,
+                           uint64_t seed, float* rays8, int64_t cap) {
+    std::vector<float> rgb((size_t)width * height * 3, 0.0f), got;
+    std::vector<int32_t> passes((size_t)width * height, 0);
+    render_impl(s, cam, lights, n_lights, width, height, x0, y0, w, h, first_sample, n_samples, seed, rgb.data(),
+                passes.data(), nullptr, 1, false, &got);
+    const int64_t n = (int64_t)(got.size() / 8);
+    if (rays8 && cap > 0) memcpy(rays8, got.data(), (size_t)(n < cap ? n : cap) * 8 * sizeof(float));
+    return n;
 }
 
 /* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for rays of the caller's own.

@@ -99,19 +99,30 @@ void orc_camera_rays(const orc_camera* cam, int width, int height, int x0, int y
 
 /* Integrator::perform_pass over a rectangle for samples [first_sample, first_sample+n_samples)
  * (integrator.cpp:211-275), accumulating into rgb_sum (W*H*3) and passes (W*H), which the
- * caller zeroes.  ray_counts[0] += closest-hit casts, [1] += shadow casts (may be NULL). */
+ * caller zeroes.  ray_counts (3 words, may be NULL): [0] += closest-hit casts, [1] += shadow casts,
+ * [2] += the shadow casts whose light sample has a non-zero weight (bookkeeping for the GPU
+ * renderer, which counts the others but does not trace them). */
 void orc_render(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights,
                 int width, int height, int x0, int y0, int w, int h,
                 uint32_t first_sample, uint32_t n_samples, uint64_t seed,
                 float* rgb_sum, int32_t* passes, uint64_t* ray_counts, int threads);
 
-/* Same render, additionally counting the work of the reference's tree walk: work_counts[0..5] +=
+/* Same render, additionally counting the work of the reference's tree walk: work_counts[0..6] +=
  * closest casts, shadow casts, box tests and triangle tests of the closest casts, box tests
- * and triangle tests of the shadow casts (reference visit order, no extra pruning). */
+ * and triangle tests of the shadow casts (reference visit order, no extra pruning), and the
+ * shadow casts whose light sample has a non-zero weight (the ones the GPU renderer traces). */
 void orc_render_counting(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights,
                          int width, int height, int x0, int y0, int w, int h,
                          uint32_t first_sample, uint32_t n_samples, uint64_t seed,
                          float* rgb_sum, int32_t* passes, uint64_t* work_counts, int threads);
+
+/* The same render on one thread, handing back every ray it casts, in casting order: 8 floats per
+ * ray -- origin, direction, light distance (0 for a closest-hit cast), tag (0 closest-hit cast,
+ * 1 shadow cast of a light sample with non-zero weight, 2 shadow cast of a zero-weight sample).
+ * Returns the number of rays cast; rays beyond `cap` are counted but not stored. */
+int64_t orc_render_capture(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights,
+                           int width, int height, int x0, int y0, int w, int h,
+                           uint32_t first_sample, uint32_t n_samples, uint64_t seed, float* rays8, int64_t cap);
 
 /* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for n given rays (origins and
  * dirs are n*3 floats, directions used as given): rgb = n*3 floats.  ids (NULL: the ray's number)

@@ -131,3 +131,57 @@ extern "C" int emul_step_trace(const pt_flat_scene* sc, const float* o, const fl
     }
     return n;
 }
+
+/* What the device walks FETCH, counted with the same lane logic: one node record per interior-node
+ * step and one triangle record per triangle step (the kernels load exactly one record per step
+ * when they test one triangle per round).  rays8 holds n rays of 8 floats: origin, direction, light
+ * distance, tag (0: closest-hit cast; 1: shadow cast that is traced; anything else: skipped).
+ * counts[0..3] += closest-hit casts: rays, node records, triangle records, stack pops
+ * counts[4..7] += shadow casts answered by the any-hit walk (light at distance >= 1): the same four
+ * counts[8..11] += shadow casts that need the closest hit (nearer lights): the same four */
+namespace {
+struct CountingMem {
+    CpuMem mem;
+    mutable uint64_t nodes = 0, tris = 0;
+    void load_node(uint32_t i, ptc::NodeData& n) const { nodes++; mem.load_node(i, n); }
+    void load_tri(uint32_t k, ptc::TriData& t) const { tris++; mem.load_tri(k, t); }
+};
+
+template <bool ANYHIT>
+uint64_t count_lane(const CountingMem& mem, const pt_flat_scene* sc, const ptc::Ray9& r) {
+    ptc::Lane L;
+    L.r = r;
+    CpuStack st;
+    uint64_t pops = 0;
+    const ptc::RootBox root = root_of(sc);
+    ptc::lane_start(L, sc->root_ref, root, ptc::root_is_tame(root));
+    while (!ptc::lane_finished(L)) {
+        if (ptc::lane_has_leaf(L)) { ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L), tr); ptc::lane_tri<ANYHIT>(L, tr); }
+        else if (ptc::lane_has_node(L)) {
+            ptc::NodeData nd; mem.load_node(L.cur, nd);
+            if (L.tame) ptc::lane_node<ANYHIT, true>(L, nd, st); else ptc::lane_node<ANYHIT, false>(L, nd, st);
+        } else { ptc::lane_pop<ANYHIT>(L, st); pops++; }
+    }
+    return pops;
+}
+} // namespace
+
+extern "C" int emul_work_counts(const pt_flat_scene* sc, uint64_t n, const float* rays8, uint64_t* counts) {
+    if (sc->n_tris == 0) return 0;
+    CountingMem mem; mem.mem.nodes = sc->nodes; mem.mem.tris = sc->tris;
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = rays8 + 8 * i;
+        ptc::Ray9 r;
+        r.ox = q[0]; r.oy = q[1]; r.oz = q[2]; r.dx = q[3]; r.dy = q[4]; r.dz = q[5];
+        ptc::ray_set_recip(r);
+        int cls;
+        if (q[7] == 0.0f) cls = 0;
+        else if (q[7] == 1.0f) cls = q[6] >= 1.0f ? 1 : 2;
+        else continue;
+        mem.nodes = 0; mem.tris = 0;
+        const uint64_t pops = cls == 1 ? count_lane<true>(mem, sc, r) : count_lane<false>(mem, sc, r);
+        uint64_t* c = counts + 4 * cls;
+        c[0] += 1; c[1] += mem.nodes; c[2] += mem.tris; c[3] += pops;
+    }
+    return 0;
+}

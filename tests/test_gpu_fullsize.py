@@ -100,6 +100,7 @@ def test_full_frame_render(big):
     got, got_p = film.read()
     assert np.array_equal(got_p, want_p)
     assert (st3.closest_rays, st3.shadow_rays) == (int(counts[0]), int(counts[1]))
+    assert st3.shadow_rays_traced == int(counts[2])
     rows = slice(536, 544)
     assert np.array_equal(got[rows].view(np.uint32), full[rows].view(np.uint32))   # a band is part of the frame
     err = np.abs(got - want)

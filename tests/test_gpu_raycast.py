@@ -79,6 +79,7 @@ def test_render_matches_oracle(scene_small):
     assert np.array_equal(passes, want_p)
     assert st.camera_samples == W * H * S
     assert st.closest_rays == int(want_counts[0]) and st.shadow_rays == int(want_counts[1])
+    assert st.shadow_rays_traced == int(want_counts[2])   # the light samples with a non-zero weight
     # Paths are identical ray for ray (same hits, same random stream); only the order in which
     # the bounce terms are summed differs (0.8*(0.8*x) nested in the oracle, a running
     # throughput on the GPU), so the tolerance is a few ulp of the pixel value.
