@@ -59,7 +59,7 @@ tests/native/_build/api_check: tests/native/api_check.cpp include/pt_render.h $(
 tests/native/_build/libpt_hip_smallstack.so: $(HIP_SRCS) $(HIP_HDRS)
 	mkdir -p tests/native/_build
 	$(HIPCC) $(HIPFLAGS) -DSTACK_LDS=4 -shared -o $@ $(HIP_SRCS)
-tests/native/_build/libtraverse_emul.so: tests/native/traverse_emul.cpp $(PKG)/csrc/traverse_core.h include/pt_hip.h
+tests/native/_build/libtraverse_emul.so: tests/native/traverse_emul.cpp $(PKG)/csrc/traverse_core.h $(PKG)/csrc/qnode_build.h include/pt_hip.h
 	mkdir -p tests/native/_build
 	$(CXX) $(HOSTFLAGS) -I$(PKG)/csrc -shared -o $@ tests/native/traverse_emul.cpp
 

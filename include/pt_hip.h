@@ -271,16 +271,21 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
                      const pt_tile_pass* passes, int n_passes, uint64_t seed,
                      pt_render_stats* stats);
 
-/* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for n rays of the caller's own:
- * the radiance along each, rgb[3*i..3*i+2].  Host arrays; directions are used as given (the
+/* Integrator::cast_ray(ray, recursions, branches) (integrator.cpp:51-156) for n rays of the caller's
+ * own: the radiance along each, rgb[3*i..3*i+2].  Host arrays; directions are used as given (the
  * reference's Ray constructor normalises, this call does not).  Of the camera only sky_color,
  * bounce_mode and shadow_mode are read.  Ray i draws its light samples from the random stream
  * keyed by stream_ids[i] (NULL: i) where a rendered path has its pixel number, and by `sample`;
- * recursions is 0..10 (perform_pass uses 10).  Waits for the result; stats may be NULL. */
+ * recursions is 0..10 (perform_pass uses 10).  branches (perform_pass uses 1; at most
+ * PT_MAX_BRANCHES): the bounce term of the first hit is the mean of that many sub-paths, each
+ * weighted (1.0/branches)*0.8 (:77, :107) and drawing from random streams of its own; 0 or less:
+ * no bounce term, as the reference's loop then does not run.  Waits for the result; stats may be
+ * NULL. */
+#define PT_MAX_BRANCHES 16
 int pt_cast_rays(pt_scene* s, const pt_camera* cam, const pt_light* lights, int n_lights, uint64_t n,
                  const float* ox, const float* oy, const float* oz,
                  const float* dx, const float* dy, const float* dz,
-                 const uint32_t* stream_ids, uint32_t sample, int recursions, uint64_t seed,
+                 const uint32_t* stream_ids, uint32_t sample, int recursions, int branches, uint64_t seed,
                  float* rgb, pt_render_stats* stats);
 
 /* The jittered camera rays of sample `sample` for the rectangle, row-major, as SoA device

@@ -192,10 +192,10 @@ struct Integrator {
     ~Integrator();
     Ray get_ray_for_pixel(int x, int y);
     /* Radiance along one ray of the caller's own (integrator.h:54, integrator.cpp:51-156), traced
-     * on this integrator's GPU as a one-path batch.  recursions 0..10.  The reference averages
-     * `branches` independent estimates of the bounce term at the first hit; here every call is
-     * one estimate whatever `branches` says (same expectation).  Each call draws from a stream
-     * of its own (seed, call number), so repeated calls give independent samples. */
+     * on this integrator's GPU as a one-path batch.  recursions 0..10.  As in the reference, the
+     * bounce term of the first hit is the mean of `branches` sub-paths, each weighted
+     * (1.0/branches)*0.8 (at most PT_MAX_BRANCHES; 0 or less: no bounce term).  Each call draws from
+     * a stream of its own (seed, call number), so repeated calls give independent samples. */
     Color cast_ray(const Ray& ray, int recursions, int branches);
     /* integrator.h:50-51 has a public std::mt19937 `engine` that callers may re-seed
      * (engine.seed(k)); this stands in for it: seeding it sets `seed` and restarts the

@@ -66,7 +66,7 @@ def lib():
         L.orc_render_counting.argtypes = L.orc_render.argtypes
         L.orc_render_capture.restype = i64
         L.orc_render_capture.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, u32, u32, u64, vp, i64]
-        L.orc_cast_rays.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp, u32, i32, u64, vp, vp]
+        L.orc_cast_rays.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp, u32, i32, i32, u64, vp, vp]
         L.orc_tonemap.argtypes = [vp, vp, i64, C.c_float, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_uniform01.restype = C.c_double
@@ -219,16 +219,16 @@ class Scene:
         lib().orc_render_capture(*args, _p(out), n)
         return out
 
-    def cast_rays(self, cam, lights, o, d, ids=None, sample=0, recursions=10, seed=1):
-        """Integrator::cast_ray for given rays: (rgb [n,3], [closest casts, shadow casts])."""
+    def cast_rays(self, cam, lights, o, d, ids=None, sample=0, recursions=10, seed=1, branches=1):
+        """Integrator::cast_ray for given rays: (rgb [n,3], [closest casts, shadow casts, weighted shadow casts])."""
         o = _f32(o).reshape(-1, 3)
         d = _f32(d).reshape(-1, 3)
         rgb = np.zeros((o.shape[0], 3), dtype=np.float32)
-        counts = np.zeros(2, dtype=np.uint64)
+        counts = np.zeros(3, dtype=np.uint64)
         idarr = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
         larr = make_lights(lights)
         lib().orc_cast_rays(self.h, C.byref(cam), larr, len(lights), o.shape[0], _p(o), _p(d),
-                            _p(idarr) if idarr is not None else None, sample, recursions, seed, _p(rgb), _p(counts))
+                            _p(idarr) if idarr is not None else None, sample, recursions, branches, seed, _p(rgb), _p(counts))
         return rgb, counts
 
 

@@ -675,6 +675,9 @@ struct PathCtx {
      * 1 shadow cast with a non-zero weight, 2 shadow cast with zero weight). */
     uint64_t shadow_weighted = 0;
     std::vector<float>* capture = nullptr;
+    /* Added to the stream numbers of the bounce draws and of the light draws below the first hit:
+     * 256 * k for sub-path k of a cast_ray call with several branches, 0 otherwise. */
+    uint32_t stream_off = 0;
 };
 
 inline void capture_ray(PathCtx& ctx, const Ray& r, float dist, float tag) {
@@ -689,8 +692,10 @@ inline bool scene_ray_test(const Scene* s, const Ray& ray, Hit& h, Counters* cn 
     return node_ray_test<false>(s->root, s->mesh, c, h, nullptr);
 }
 
-/* integrator.cpp:51-156.  depth = 10 - recursions. */
-V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
+/* integrator.cpp:51-156.  depth counts path vertices from the first cast (0).  With the counter-based
+ * random stream the `branches` sub-paths of the first hit (:77) need streams of their own to be
+ * independent estimates: sub-path k adds 256*k to its stream numbers (k = 0: the plain streams). */
+V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth, int branches = 1) {
     Hit h;
     ctx.closest_casts++;
     capture_ray(ctx, ray, 0.0f, 0.0f);
@@ -702,16 +707,18 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
     V3 hit = ray.o + h.t * ray.d;                                   /* :69 */
     hit = project_to_altitude(tr, hit, (float)1e-3);                /* :72 */
     V3 reflection = normalized(ray.d - (2.0f * dot(n, ray.d)) * n); /* :73-74 */
-    if (recursions > 0) {
+    for (int branch = 0; recursions > 0 && branch < branches; branch++) { /* :76-77 */
         /* :79-84 draw a scatter direction that :104 then replaces by the mirror direction; the
          * draws only advance the reference's engine and have no counterpart in a counter-based
          * stream.  Ray's constructor normalises the (already unit) direction again. */
+        const uint32_t outer_off = ctx.stream_off;
+        if (branches > 1) ctx.stream_off = 256u * (uint32_t)branch;
         V3 scatter_direction = reflection;
         if (ctx.bounce_mode == 1) {
             /* :79-84 as written, kept instead of being overwritten at :104.  sample_unit_sphere
              * (utils.cpp:177-185) is three standard normals, normalised; stream 1 + depth. */
             uint32_t sw[4];
-            rng_words(ctx.seed, ctx.pixel, ctx.sample, 1u + (uint32_t)depth, sw);
+            rng_words(ctx.seed, ctx.pixel, ctx.sample, 1u + (uint32_t)depth + ctx.stream_off, sw);
             V3 local = normalized(mk(normal_from_word(sw[0]), normal_from_word(sw[1]), normal_from_word(sw[2])));
             local.x = fabsf(local.x);                                   /* :80 */
             V3 d1 = normalized(tr.e1);                                  /* :82 */
@@ -719,12 +726,13 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth) {
             scatter_direction = (local.x * tr.normal + local.y * d1) + local.z * d2; /* :84 */
         }
         Ray scattered = make_ray(hit, scatter_direction);
-        float w = (float)((1.0 / 1) * 0.8);
-        energy = energy + w * cast_ray(ctx, scattered, recursions - 1, depth + 1); /* :107 */
+        float w = (float)((1.0 / branches) * 0.8);
+        energy = energy + w * cast_ray(ctx, scattered, recursions - 1, depth + 1, 1); /* :107 */
+        ctx.stream_off = outer_off;
     }
     for (int l = 0; l < ctx.n_lights; l++) { /* :112-148 */
         uint32_t w[4];
-        rng_words(ctx.seed, ctx.pixel, ctx.sample, 16u + 16u * (uint32_t)depth + (uint32_t)l, w);
+        rng_words(ctx.seed, ctx.pixel, ctx.sample, 16u + 16u * (uint32_t)depth + (uint32_t)l + ctx.stream_off, w);
         V3 jitter = mk(0.2f * normal_from_word(w[0]), 0.2f * normal_from_word(w[1]),
                        0.2f * normal_from_word(w[2]));
         V3 lp = mk(ctx.lights[l].position[0], ctx.lights[l].position[1], ctx.lights[l].position[2]);
@@ -1030,12 +1038,13 @@ int64_t orc_render_capture(const orc_scene* s, const orc_camera* cam, const orc_
     return n;
 }
 
-/* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for rays of the caller's own.
- * Directions are used as given.  Ray i draws from the stream keyed by ids[i] (NULL: i) in place of
- * a pixel number, and by `sample`.  counts = {closest casts, shadow casts}. */
+/* Integrator::cast_ray(ray, recursions, branches) (integrator.cpp:51-156) for rays of the caller's
+ * own.  Directions are used as given.  Ray i draws from the stream keyed by ids[i] (NULL: i) in place
+ * of a pixel number, and by `sample`.  counts = {closest casts, shadow casts, shadow casts of light
+ * samples with non-zero weight}. */
 void orc_cast_rays(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int64_t n,
                    const float* origins, const float* dirs, const uint32_t* ids, uint32_t sample, int recursions,
-                   uint64_t seed, float* rgb, uint64_t* counts) {
+                   int branches, uint64_t seed, float* rgb, uint64_t* counts) {
     if (n_lights > MAX_LIGHTS) n_lights = MAX_LIGHTS;
     PathCtx ctx;
     ctx.scene = &s->s; ctx.lights = lights; ctx.n_lights = n_lights;
@@ -1048,10 +1057,10 @@ void orc_cast_rays(const orc_scene* s, const orc_camera* cam, const orc_light* l
         ctx.pixel = ids ? ids[i] : (uint32_t)i;
         ctx.sample = sample;
         Ray r = input_ray(origins, dirs, i, 0);
-        V3 c = cast_ray(ctx, r, recursions, 0);
+        V3 c = cast_ray(ctx, r, recursions, 0, branches);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
     }
-    if (counts) { counts[0] = ctx.closest_casts; counts[1] = ctx.shadow_casts; }
+    if (counts) { counts[0] = ctx.closest_casts; counts[1] = ctx.shadow_casts; counts[2] = ctx.shadow_weighted; }
 }
 
 /* canvas.cpp:39-45 */

@@ -124,13 +124,14 @@ int64_t orc_render_capture(const orc_scene* s, const orc_camera* cam, const orc_
                            int width, int height, int x0, int y0, int w, int h,
                            uint32_t first_sample, uint32_t n_samples, uint64_t seed, float* rays8, int64_t cap);
 
-/* Integrator::cast_ray(ray, recursions, 1) (integrator.cpp:51-156) for n given rays (origins and
- * dirs are n*3 floats, directions used as given): rgb = n*3 floats.  ids (NULL: the ray's number)
- * and sample key the random stream where a rendered path has its pixel and sample numbers.
- * counts = {closest casts, shadow casts}. */
+/* Integrator::cast_ray(ray, recursions, branches) (integrator.cpp:51-156) for n given rays (origins
+ * and dirs are n*3 floats, directions used as given): rgb = n*3 floats.  ids (NULL: the ray's number)
+ * and sample key the random stream where a rendered path has its pixel and sample numbers; sub-path
+ * k of a first hit with several branches adds 256*k to its stream numbers.
+ * counts = {closest casts, shadow casts, shadow casts of light samples with non-zero weight}. */
 void orc_cast_rays(const orc_scene* s, const orc_camera* cam, const orc_light* lights, int n_lights, int64_t n,
                    const float* origins, const float* dirs, const uint32_t* ids, uint32_t sample, int recursions,
-                   uint64_t seed, float* rgb, uint64_t* counts);
+                   int branches, uint64_t seed, float* rgb, uint64_t* counts);
 
 /* Canvas::get_pixel for a whole image (canvas.cpp:39-45): rgb8 = W*H*3 bytes. */
 void orc_tonemap(const float* rgb_sum, const int32_t* passes, int64_t n_pixels, float gain,

@@ -37,6 +37,7 @@
 #include "pt_hip.h"
 #include "shade_core.h"
 #include "traverse_core.h"
+#include "qnode_build.h"
 
 using namespace ptc;
 
@@ -63,6 +64,11 @@ struct DScene {
     uint32_t root_ref;
     uint32_t n_tris;
     RootBox root;
+    /* quantised interior nodes of the any-hit walks (traverse_core.h "q-nodes"), in the same allocation */
+    uint32_t q_off;       /* byte offset of the 32-byte q-node records */
+    uint32_t q_root;      /* the root's position for walks on q-nodes; PT_REF_NONE: the scene has none */
+    uint32_t q_root_exact; /* ... for rays that must stay on exact records (not tame) */
+    QGrid grid;
 };
 
 struct RaySoA {
@@ -228,9 +234,13 @@ struct TraceArgs {
  * one atomic on the queue head per chunk).  The loop ends when the queue is empty and every
  * lane is idle, so the grid always drains.
  */
-template <int MODE, int TPR = 1>
+template <int MODE, int TPR = 1, bool QN = false>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 1 ? TRACE_WAVES_PER_EU : TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU_3))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED);
+    /* QN: interior nodes whose children are both interior are read as 32-byte quantised records (two
+     * load pieces instead of four); any-hit walks only, whose answer does not depend on which
+     * enclosing boxes the interior levels are tested against (traverse_core.h "q-nodes") */
+    static_assert(!QN || ANY, "q-nodes are for the any-hit walks");
     constexpr bool CLOSEST_OUT = (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT);
     __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
     const uint32_t n = *a.d_count * a.count_mul;
@@ -319,7 +329,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             if (MODE == TRACE_SHADOW_ANY && !(dist >= 1.0f)) defer = true;
             else {
                 ray_set_recip(L.r);
-                lane_start(L, sc.root_ref, sc.root, scene_tame);
+                /* with q-nodes every node position is in their numbering; rays that are not tame start
+                 * on the exact root and stay on exact records */
+                const uint32_t root_pos = QN ? ((scene_tame && ray_is_tame(L.r)) ? sc.q_root : sc.q_root_exact) : sc.root_ref;
+                lane_start(L, root_pos, sc.root, scene_tame);
                 /* a triangle counts only if it is strictly nearer than the best so far: starting
                  * from the bound instead of infinity makes that "nearer than the light" */
                 if (MODE == TRACE_SHADOW_BOUNDED) L.best.t = dist;
@@ -357,6 +370,26 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             }
         }
         {
+            if (QN && rec_node) {
+                /* q-node lanes expand their eight words into the exact record's layout, in place and
+                 * back to front (no word is overwritten before it has been read), so that the step
+                 * below reads one set of registers whatever the record was */
+                if (L.cur < PT_Q_EXACT_BASE) {
+                    NodeData t;
+                    const uint32_t w[8] = {__float_as_uint(q0.x), __float_as_uint(q0.y), __float_as_uint(q0.z), __float_as_uint(q0.w),
+                                           __float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z), __float_as_uint(q1.w)};
+                    qnode_decode(w, sc.grid, t);
+                    q3.x = __uint_as_float(t.lo_ref); q3.y = __uint_as_float(t.hi_ref); q3.z = __uint_as_float(t.axis);
+                    q2.z = t.hi[2][0]; q2.w = t.hi[2][1]; q2.x = t.hi[1][0]; q2.y = t.hi[1][1];
+                    q1.z = t.hi[0][0]; q1.w = t.hi[0][1]; q1.x = t.lo[2][0]; q1.y = t.lo[2][1];
+                    q0.z = t.lo[1][0]; q0.w = t.lo[1][1]; q0.x = t.lo[0][0]; q0.y = t.lo[0][1];
+                } else {
+                    /* an exact record's interior children are exact records too */
+                    const uint32_t lo_ref = __float_as_uint(q3.x), hi_ref = __float_as_uint(q3.y);
+                    q3.x = __uint_as_float(ref_is_leaf(lo_ref) ? lo_ref : lo_ref + PT_Q_EXACT_BASE);
+                    q3.y = __uint_as_float(ref_is_leaf(hi_ref) ? hi_ref : hi_ref + PT_Q_EXACT_BASE);
+                }
+            }
             NodeData nd;
             nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
             nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
@@ -384,10 +417,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
         rec_tri = active && lane_has_leaf(L);
         rec_node = active && lane_has_node(L);
         if (rec_tri || rec_node) {
-            const uint32_t off = rec_tri ? sc.tris_off + lane_leaf_pos(L) * (uint32_t)sizeof(pt_tri_isect) : L.cur * (uint32_t)sizeof(pt_flat_node);
+            const bool rec_exact = !QN || L.cur >= PT_Q_EXACT_BASE;   /* (for a node) an exact 64-byte record */
+            const uint32_t off = rec_tri ? sc.tris_off + lane_leaf_pos(L) * (uint32_t)sizeof(pt_tri_isect)
+                               : !QN ? L.cur * (uint32_t)sizeof(pt_flat_node)
+                               : rec_exact ? (L.cur - PT_Q_EXACT_BASE) * (uint32_t)sizeof(pt_flat_node) : sc.q_off + L.cur * 32u;
             const float4* rec = (const float4*)(sc.geom + off);
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
-            if (rec_node) q3 = rec[3];
+            q0 = rec[0]; q1 = rec[1];
+            if (!QN || rec_tri || rec_exact) q2 = rec[2];
+            if (rec_node && rec_exact) q3 = rec[3];
             if (TPR > 1) {
                 const uint32_t after = sc.n_tris - 1u - lane_leaf_pos(L);   /* records that follow in the array */
                 rec_more = rec_tri ? (int)min(after, (uint32_t)(TPR - 1)) : 0;
@@ -701,8 +738,21 @@ __global__ __launch_bounds__(256) void k_camera_rays(CamParams cam, int x0, int 
  * shadow queue is 64 consecutive words instead of a stride-n_lights scatter. */
 #define SHADE_FRAME_WORDS 12
 #define SHADE_GROUP 3   /* light samples per thread between two compactions of the shadow-ray queue */
+/* One of the `branches` estimates of Integrator::cast_ray(ray, recursions, branches) (reference
+ * integrator.cpp:76-108): the bounce term of the FIRST hit is the mean of `branches` sub-paths, each
+ * weighted (1.0/branches)*0.8.  Estimate k is one run of the bounce loop with that weight on the
+ * first bounce and its own random streams (stream_off = 256*k on the bounce draws and on the light
+ * draws below the first hit); estimates k > 0 leave out what belongs to the first hit itself (its
+ * light samples, the sky of a ray that hits nothing), which estimate 0 has already added. */
+struct BranchOpts {
+    float first_weight;    /* (float)((1.0/branches)*0.8); 0.8f for the renderer */
+    uint32_t stream_off;
+    int skip_first;
+};
+
 __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam, const DLight* lights, uint32_t n_lights,
-                                                         uint32_t depth, int last_depth, int trace_all, uint64_t seed, RenderBuffers b) {
+                                                         uint32_t depth, int last_depth, int trace_all, uint64_t seed, BranchOpts br,
+                                                         RenderBuffers b) {
     __shared__ uint32_t s_wave[BLOCK_COMPACT_WORDS];
     __shared__ float s_frame[SHADE_FRAME_WORDS][STREAM_BLOCK];
     __shared__ uint32_t s_group[SHADE_GROUP][STREAM_BLOCK / 64];
@@ -723,7 +773,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             /* One read-modify-write of the path's radiance: first the visible light samples of
              * the previous path vertex (entry i of this queue is slot i of that depth's samples),
              * lights in order, then the sky if this ray left the scene (reference integrator.cpp:153). */
-            const bool sky_adds = !hit && (cam.sky.x != 0.0f || cam.sky.y != 0.0f || cam.sky.z != 0.0f);
+            const bool sky_adds = !hit && (cam.sky.x != 0.0f || cam.sky.y != 0.0f || cam.sky.z != 0.0f) && !(br.skip_first && depth == 0);
             const bool lights_add = depth > 0 && n_lights > 0;
             if (sky_adds || lights_add) {
                 float r = b.rad_r[path], g = b.rad_g[path], bl = b.rad_b[path];
@@ -763,11 +813,11 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
             b.qpath[nxt][slot] = path;
             if (!last_depth) {
                 V3f bo, bd;
-                if (cam.bounce_mode == PT_BOUNCE_LAMBERT) bounce_ray_lambert(f, st, seed, pixel, sample, depth, bo, bd);
+                if (cam.bounce_mode == PT_BOUNCE_LAMBERT) bounce_ray_lambert(f, st, seed, pixel, sample, depth, br.stream_off, bo, bd);
                 else bounce_ray(f, bo, bd);
                 b.q[nxt].ox[slot] = bo.x; b.q[nxt].oy[slot] = bo.y; b.q[nxt].oz[slot] = bo.z;
                 b.q[nxt].dx[slot] = bd.x; b.q[nxt].dy[slot] = bd.y; b.q[nxt].dz[slot] = bd.z;
-                b.thr[path] = 0.8f * thr; /* reference integrator.cpp:107 */
+                b.thr[path] = (depth == 0 ? br.first_weight : 0.8f) * thr; /* reference integrator.cpp:107 */
             }
         }
         __syncthreads();
@@ -798,11 +848,12 @@ __global__ __launch_bounds__(STREAM_BLOCK) void k_shade(DScene sc, CamParams cam
                     f.refl = v3(s_frame[6][k], s_frame[7][k], s_frame[8][k]);
                     const float thr = s_frame[9][k];
                     const uint32_t pixel = __float_as_uint(s_frame[10][k]), sample = __float_as_uint(s_frame[11][k]);
-                    LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l);
-                    const float wr = thr * ls.weight.x, wg = thr * ls.weight.y, wb = thr * ls.weight.z;
+                    LightSample ls = light_sample(f, lights[l].pos, lights[l].color, seed, pixel, sample, depth, l, depth > 0 ? br.stream_off : 0u);
+                    const bool left_out = br.skip_first && depth == 0;
+                    const float wr = left_out ? 0.0f : thr * ls.weight.x, wg = left_out ? 0.0f : thr * ls.weight.y, wb = left_out ? 0.0f : thr * ls.weight.z;
                     const size_t q = (size_t)slot0 * n_lights + j;
                     b.sh_wr[cur][q] = wr; b.sh_wg[cur][q] = wg; b.sh_wb[cur][q] = wb;
-                    trace[g] = trace_all || !(wr == 0.0f && wg == 0.0f && wb == 0.0f); /* NaN weights are traced */
+                    trace[g] = !left_out && (trace_all || !(wr == 0.0f && wg == 0.0f && wb == 0.0f)); /* NaN weights are traced */
                     if (!trace[g]) b.sh_vis[cur][q] = 0;
                     origin[g] = f.hit; dir[g] = ls.dir; dist[g] = ls.dist;
                 }
@@ -963,6 +1014,7 @@ struct pt_scene {
     uint64_t defer_cap = 0;
     int grid_closest = 0, grid_any = 0; /* resident blocks of the persistent trace kernels */
     int tris_per_round = 1;             /* 2, 3: the trace kernels that test that many triangles of a leaf per round (large leaves) */
+    bool use_qnodes = false;            /* the any-hit launches use the kernels that read quantised interior nodes */
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
     double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
@@ -1100,7 +1152,18 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     size_t sb = std::max<size_t>(flat->n_tris, 1) * sizeof(pt_tri_shade);
     const size_t tris_off = (nb + 255) & ~(size_t)255;
     if (tris_off + tb >= ((size_t)1 << 32)) return cleanup(fail(PT_ERR_LIMIT, "nodes and triangle records exceed 4 GiB"));
-    if (hipMalloc(&s->d_geom, tris_off + tb) != hipSuccess ||
+    /* Quantised interior nodes for the any-hit walks, behind the triangle records if they still fit
+     * below 4 GiB (PT_QNODES=0: do without them). */
+    ptq::QNodes qn;
+    {
+        const char* e = getenv("PT_QNODES");
+        if (!(e && atoi(e) == 0)) ptq::build_qnodes(flat, qn);
+    }
+    const size_t q_off = (tris_off + tb + 255) & ~(size_t)255;
+    const size_t qb = qn.rec.size() * sizeof(ptq::QNodeRec);
+    if (q_off + qb >= ((size_t)1 << 32)) qn.rec.clear();
+    const bool with_q = !qn.rec.empty();
+    if (hipMalloc(&s->d_geom, with_q ? q_off + qb : tris_off + tb) != hipSuccess ||
         hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, SMALL_WORDS * sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(PT_ERR_DEVICE, "hipMalloc failed for the scene arrays"));
     bool ok = true;
@@ -1109,7 +1172,13 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
         ok = ok && hipMemcpy((char*)s->d_geom + tris_off, flat->tris, flat->n_tris * sizeof(pt_tri_isect), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(s->d_shade, flat->shade, flat->n_tris * sizeof(pt_tri_shade), hipMemcpyHostToDevice) == hipSuccess;
     }
+    if (with_q) ok = ok && hipMemcpy((char*)s->d_geom + q_off, qn.rec.data(), qb, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return cleanup(fail(PT_ERR_DEVICE, "hipMemcpy failed for the scene arrays"));
+    s->use_qnodes = with_q;
+    s->d.q_off = (uint32_t)q_off;
+    s->d.q_root = with_q ? qn.root : PT_REF_NONE;
+    s->d.q_root_exact = PT_Q_EXACT_BASE + flat->root_ref;
+    s->d.grid = qn.grid;
     s->d.geom = (const char*)s->d_geom;
     s->d.tris_off = (uint32_t)tris_off;
     s->d.shade = (const float4*)s->d_shade;
@@ -1190,8 +1259,15 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     a.spill = here.spill;
     if (a.count_mul == 0) a.count_mul = 1;
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW, here.stream);
-    const dim3 grid(trace_grid(s, MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED));
-    if (s->tris_per_round == 2) hipLaunchKernelGGL((k_trace<MODE, 2>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
+    const dim3 grid(trace_grid(s, ANY));
+    if (ANY && s->use_qnodes) {
+        constexpr int QMODE = ANY ? MODE : TRACE_SHADOW_ANY;   /* (keeps the closest-hit instantiations of this function valid) */
+        if (s->tris_per_round == 2) hipLaunchKernelGGL((k_trace<QMODE, 2, true>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+        else if (s->tris_per_round == 3) hipLaunchKernelGGL((k_trace<QMODE, 3, true>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+        else hipLaunchKernelGGL((k_trace<QMODE, 1, true>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    }
+    else if (s->tris_per_round == 2) hipLaunchKernelGGL((k_trace<MODE, 2>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     else if (s->tris_per_round == 3) hipLaunchKernelGGL((k_trace<MODE, 3>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     else hipLaunchKernelGGL((k_trace<MODE, 1>), grid, dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     HIP_TRY(hipGetLastError());
@@ -1211,6 +1287,11 @@ static int init_trace_launch(pt_scene* s) {
     } else {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_trace<TRACE_CLOSEST_FLAT, 1>, TRACE_BLOCK, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 1>, TRACE_BLOCK, 0));
+    }
+    if (s->use_qnodes) {   /* the any-hit kernels that will actually run */
+        if (s->tris_per_round == 2) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 2, true>, TRACE_BLOCK, 0));
+        else if (s->tris_per_round == 3) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 3, true>, TRACE_BLOCK, 0));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_trace<TRACE_SHADOW_ANY, 1, true>, TRACE_BLOCK, 0));
     }
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) { per_cu_c = v; per_cu_a = v; } }
     per_cu_c = std::max(1, std::min(per_cu_c, 8));
@@ -1579,7 +1660,7 @@ static void fill_cam(CamParams& c, const pt_camera* cam, int width, int height) 
  * is the reference's recursions = max_depth - d.  Everything is queued on ctx.stream with no host
  * round trip. */
 static int enqueue_bounces(pt_scene* s, RenderBuffers& b, const LaunchCtx& ctx, const CamParams& cam, const DLight* d_lights,
-                           uint32_t n_lights, uint32_t max_depth, uint64_t seed) {
+                           uint32_t n_lights, uint32_t max_depth, uint64_t seed, BranchOpts br = BranchOpts{0.8f, 0u, 0}) {
     hipStream_t st = ctx.stream;
     const int light_grid = s->num_cus * 8;
     const int shade_grid = s->num_cus * SHADE_GRID_MUL;
@@ -1598,7 +1679,7 @@ static int enqueue_bounces(pt_scene* s, RenderBuffers& b, const LaunchCtx& ctx, 
         {
             ScopedTimer tm(s, PT_KERNEL_SHADE, st);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, st, s->d, cam, d_lights, n_lights, depth,
-                               depth == max_depth ? 1 : 0, trace_all, seed, b);
+                               depth == max_depth ? 1 : 0, trace_all, seed, br, b);
             HIP_TRY(hipGetLastError());
         }
         if (n_lights > 0) {
@@ -2057,15 +2138,19 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
 
 int pt_cast_rays(pt_scene* s, const pt_camera* cam, const pt_light* lights, int n_lights, uint64_t n, const float* ox,
                  const float* oy, const float* oz, const float* dx, const float* dy, const float* dz, const uint32_t* stream_ids,
-                 uint32_t sample, int recursions, uint64_t seed, float* rgb, pt_render_stats* stats) {
+                 uint32_t sample, int recursions, int branches, uint64_t seed, float* rgb, pt_render_stats* stats) {
     if (!s || !cam || n_lights < 0 || (n_lights > 0 && !lights)) return fail(PT_ERR_INVALID, "bad argument");
     if (stats) memset(stats, 0, sizeof(*stats));
     if (n == 0) return PT_OK;
     if (!ox || !oy || !oz || !dx || !dy || !dz || !rgb) return fail(PT_ERR_INVALID, "null array");
     if (n_lights > PT_MAX_LIGHTS) return fail(PT_ERR_LIMIT, "more than PT_MAX_LIGHTS lights");
     if (recursions < 0 || recursions > 10) return fail(PT_ERR_LIMIT, "recursions outside 0..10");
+    if (branches > PT_MAX_BRANCHES) return fail(PT_ERR_LIMIT, "more than PT_MAX_BRANCHES branches");
     if (cam->bounce_mode > PT_BOUNCE_LAMBERT || cam->shadow_mode > PT_SHADOW_BOUNDED) return fail(PT_ERR_INVALID, "unknown bounce_mode or shadow_mode");
     if (n * (uint64_t)std::max(n_lights, 1) > PT_MAX_RAYS_PER_CALL || n > ((uint64_t)1 << 28)) return fail(PT_ERR_LIMIT, "too many rays in one pt_cast_rays call");
+    /* the loop over branches at integrator.cpp:77 does not run for branches <= 0: no bounce term */
+    if (branches <= 0) { recursions = 0; branches = 1; }
+    if (recursions == 0) branches = 1;
     int rc = set_device(s);
     if (rc) return rc;
     /* scratch that lives for the call */
@@ -2089,33 +2174,42 @@ int pt_cast_rays(pt_scene* s, const pt_camera* cam, const pt_light* lights, int 
         hl[l].color = v3(lights[l].color[0], lights[l].color[1], lights[l].color[2]);
     }
     if (n_lights > 0) HIP_TRY(hipMemcpyAsync(sc.ln.d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, st));
-    HIP_TRY(hipMemcpyAsync(b.cnt + CNT_QUEUE, &n32, 4, hipMemcpyHostToDevice, st));
-    const float* src[6] = {ox, oy, oz, dx, dy, dz};
-    float* dst[6] = {b.q[0].ox, b.q[0].oy, b.q[0].oz, b.q[0].dx, b.q[0].dy, b.q[0].dz};
-    for (int k = 0; k < 6; k++) HIP_TRY(hipMemcpyAsync(dst[k], src[k], n * 4, hipMemcpyHostToDevice, st));
     if (stream_ids) {
         HIP_TRY(hipMalloc((void**)&sc.d_ids, n * 4));
         HIP_TRY(hipMemcpyAsync(sc.d_ids, stream_ids, n * 4, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_seed_paths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n32, sc.d_ids, sample, b);
-    HIP_TRY(hipGetLastError());
+    const float* src[6] = {ox, oy, oz, dx, dy, dz};
+    float* dst[6] = {b.q[0].ox, b.q[0].oy, b.q[0].oz, b.q[0].dx, b.q[0].dy, b.q[0].dz};
     const LaunchCtx ctx{st, s->d_spill};
-    rc = enqueue_bounces(s, b, ctx, cp, sc.ln.d_lights, (uint32_t)n_lights, (uint32_t)recursions, seed);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(r.data(), b.rad_r, n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(g.data(), b.rad_g, n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(bl.data(), b.rad_b, n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(sc.ln.h_cnt, b.cnt, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (uint64_t i = 0; i < n; i++) { rgb[3 * i] = r[(size_t)i]; rgb[3 * i + 1] = g[(size_t)i]; rgb[3 * i + 2] = bl[(size_t)i]; }
-    if (stats) {
-        const uint32_t* h = sc.ln.h_cnt;
-        stats->camera_samples = n;
-        for (int d = 0; d <= recursions; d++) {
-            stats->closest_rays += h[CNT_QUEUE + d];
-            stats->shadow_rays += (uint64_t)h[CNT_QUEUE + d + 1] * (uint64_t)n_lights;
-            if (n_lights) stats->shadow_rays_traced += h[CNT_SHADOW(d)];
+    for (uint64_t i = 0; i < 3 * n; i++) rgb[i] = 0.0f;
+    if (stats) stats->camera_samples = n;
+    /* One run of the bounce loop per estimate (see BranchOpts); the estimates' radiances are summed. */
+    for (int k = 0; k < branches; k++) {
+        BranchOpts br;
+        br.first_weight = (float)((1.0 / (double)branches) * 0.8);   /* formed in double, narrowed once (integrator.cpp:107) */
+        br.stream_off = 256u * (uint32_t)k;
+        br.skip_first = k > 0 ? 1 : 0;
+        HIP_TRY(hipMemsetAsync(b.cnt, 0, CNT_WORDS * 4, st));
+        HIP_TRY(hipMemcpyAsync(b.cnt + CNT_QUEUE, &n32, 4, hipMemcpyHostToDevice, st));
+        for (int c = 0; c < 6; c++) HIP_TRY(hipMemcpyAsync(dst[c], src[c], n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_seed_paths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n32, sc.d_ids, sample, b);
+        HIP_TRY(hipGetLastError());
+        rc = enqueue_bounces(s, b, ctx, cp, sc.ln.d_lights, (uint32_t)n_lights, (uint32_t)recursions, seed, br);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(r.data(), b.rad_r, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(g.data(), b.rad_g, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(bl.data(), b.rad_b, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(sc.ln.h_cnt, b.cnt, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < n; i++) { rgb[3 * i] += r[(size_t)i]; rgb[3 * i + 1] += g[(size_t)i]; rgb[3 * i + 2] += bl[(size_t)i]; }
+        if (stats) {
+            const uint32_t* h = sc.ln.h_cnt;
+            /* the first ray and the first hit's light samples are cast once, by estimate 0 */
+            for (int d = k > 0 ? 1 : 0; d <= recursions; d++) {
+                stats->closest_rays += h[CNT_QUEUE + d];
+                stats->shadow_rays += (uint64_t)h[CNT_QUEUE + d + 1] * (uint64_t)n_lights;
+                if (n_lights) stats->shadow_rays_traced += h[CNT_SHADOW(d)];
+            }
         }
     }
     return PT_OK;

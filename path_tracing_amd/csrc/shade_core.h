@@ -109,10 +109,10 @@ PT_HD void bounce_ray(const SurfaceFrame& f, V3f& o, V3f& d) { o = f.hit; d = vu
 /* The bounce ray of the Lambertian mode (:79-84, i.e. the reference without :104): a unit-sphere
  * sample (utils.cpp:177-185: three standard normals, normalised) with its first component
  * made non-negative, taken in the triangle's frame {normal, d1, normal x d1}.  Stream 1 + depth
- * of the path's random stream supplies the three normals. */
+ * (+ stream_off, see BranchOpts in pt_hip.hip) of the path's random stream supplies the three normals. */
 PT_HD void bounce_ray_lambert(const SurfaceFrame& f, const ShadeTri& tr, uint64_t seed, uint32_t pixel, uint32_t sample,
-                              uint32_t depth, V3f& o, V3f& d) {
-    Rng4 w = rng_block(seed, pixel, sample, 1u + depth);
+                              uint32_t depth, uint32_t stream_off, V3f& o, V3f& d) {
+    Rng4 w = rng_block(seed, pixel, sample, 1u + depth + stream_off);
     V3f local = vunit(v3(normal_from_word(w.w[0]), normal_from_word(w.w[1]), normal_from_word(w.w[2])));
     local.x = __builtin_fabsf(local.x);
     V3f d2 = vcross(tr.normal, tr.d1);
@@ -132,8 +132,8 @@ PT_HD float sq(float x) { return x * x; }
 
 /* One light of the loop at :112-148 for path vertex `depth`. */
 PT_HD LightSample light_sample(const SurfaceFrame& f, V3f light_pos, V3f light_color, uint64_t seed, uint32_t pixel,
-                               uint32_t sample, uint32_t depth, uint32_t light) {
-    Rng4 w = rng_block(seed, pixel, sample, 16u + 16u * depth + light);
+                               uint32_t sample, uint32_t depth, uint32_t light, uint32_t stream_off = 0u) {
+    Rng4 w = rng_block(seed, pixel, sample, 16u + 16u * depth + light + stream_off);
     V3f jitter = v3(0.2f * normal_from_word(w.w[0]), 0.2f * normal_from_word(w.w[1]), 0.2f * normal_from_word(w.w[2]));
     V3f to_light = vsub(vadd(jitter, light_pos), f.hit);
     LightSample s;

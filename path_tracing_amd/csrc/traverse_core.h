@@ -317,6 +317,56 @@ PT_HD void lane_node(Lane& L, const NodeData& n, Stack& st) {
     lane_enter(L, next);
 }
 
+/*
+ * Quantised interior nodes for the any-hit walks ("q-nodes").
+ *
+ * The answer of an any-hit walk is order-free: it is "does the ray hit a triangle of a leaf whose
+ * box, and whose ancestors' boxes, the ray hits".  Node boxes are unions of their triangles' boxes
+ * (kdtree.cpp:60-61), so along every axis an ancestor's bounds enclose its descendants' exactly, in
+ * binary32.  The slab test's per-axis terms fl(fl(b - o) * r) are monotone in the bound b, hence for
+ * a ray whose box tests produce no NaN (a "tame" ray) a hit of a box implies a hit of every box
+ * that encloses it -- in the test's own binary32 arithmetic, not only in exact arithmetic.  So
+ *   - the leaves whose triangles the reference tests are exactly the leaves whose OWN box is hit, and
+ *   - an interior node may be tested against ANY box that encloses its true one: that can only add
+ *     visits to subtrees in which no leaf box is hit, never remove a leaf.
+ * A q-node stores the two child boxes on a 16-bit grid over the root box, rounded outwards (the
+ * builder checks the decoded binary32 values, computed as the kernel computes them, against the true
+ * bounds), in 32 bytes instead of 64.  Only nodes whose children are both interior have a q-node;
+ * a node with a leaf child keeps its exact record, so every leaf is entered through the exact test
+ * of its own box.  Below such a node the walk stays on exact records.
+ *
+ * A lane's position `cur` in this scheme: PT_REF_NONE, a leaf reference, a q-node index (below
+ * PT_Q_EXACT_BASE) or PT_Q_EXACT_BASE + an exact node's index.
+ */
+#define PT_Q_EXACT_BASE 0x02000000u     /* node positions from here on mean "exact record number (position - base)" */
+#define PT_Q_AXIS_BIT   0x40000000u     /* in a q-node's two references: bit 0 and bit 1 of the split axis */
+
+struct QGrid { float g0[3], s[3]; };    /* plane of grid step q on axis a: (float)q * s[a] + g0[a] */
+
+/* Product and sum rounded separately (no contraction), on the host as on the device: each then takes
+ * one scalar operand, which a fused multiply-add with two scalars could not. */
+PT_HD float q_plane(uint32_t q, float s, float g0) { const float p = (float)q * s; return p + g0; }
+
+/* The eight words of a q-node: six {minimum | maximum << 16} pairs (low child x, y, z, high child
+ * x, y, z), then the two child references. */
+PT_HD void qnode_decode(const uint32_t w[8], const QGrid& g, NodeData& n) {
+    n.lo[0] = pt_f2{q_plane(w[0] & 0xffffu, g.s[0], g.g0[0]), q_plane(w[0] >> 16, g.s[0], g.g0[0])};
+    n.lo[1] = pt_f2{q_plane(w[1] & 0xffffu, g.s[1], g.g0[1]), q_plane(w[1] >> 16, g.s[1], g.g0[1])};
+    n.lo[2] = pt_f2{q_plane(w[2] & 0xffffu, g.s[2], g.g0[2]), q_plane(w[2] >> 16, g.s[2], g.g0[2])};
+    n.hi[0] = pt_f2{q_plane(w[3] & 0xffffu, g.s[0], g.g0[0]), q_plane(w[3] >> 16, g.s[0], g.g0[0])};
+    n.hi[1] = pt_f2{q_plane(w[4] & 0xffffu, g.s[1], g.g0[1]), q_plane(w[4] >> 16, g.s[1], g.g0[1])};
+    n.hi[2] = pt_f2{q_plane(w[5] & 0xffffu, g.s[2], g.g0[2]), q_plane(w[5] >> 16, g.s[2], g.g0[2])};
+    n.lo_ref = w[6] & ~PT_Q_AXIS_BIT;
+    n.hi_ref = w[7] & ~PT_Q_AXIS_BIT;
+    n.axis = ((w[6] >> 30) & 1u) | ((w[7] >> 29) & 2u);
+}
+
+/* An exact record met by a walk that uses q-nodes: its interior children are exact records too. */
+PT_HD void exact_refs_to_q_space(NodeData& n) {
+    n.lo_ref = ref_is_leaf(n.lo_ref) ? n.lo_ref : n.lo_ref + PT_Q_EXACT_BASE;
+    n.hi_ref = ref_is_leaf(n.hi_ref) ? n.hi_ref : n.hi_ref + PT_Q_EXACT_BASE;
+}
+
 /* One triangle of the pending leaf, in stored order, strict '<' (:281-293). */
 template <bool ANYHIT>
 PT_HD void lane_tri(Lane& L, const TriData& tr) {

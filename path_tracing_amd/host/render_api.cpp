@@ -389,7 +389,6 @@ Ray Integrator::get_ray_for_pixel(int x, int y) { /* integrator.cpp:197-209 */
 void Integrator::SeedHandle::seed(uint64_t value) { owner->seed = value; owner->cast_calls = 0; }
 
 Color Integrator::cast_ray(const Ray& ray, int recursions, int branches) {
-    (void)branches;
     pt_scene* ds = scene && scene->tree ? scene->tree->device_scene(device) : nullptr;
     if (!ds) return Color(0, 0, 0);
     pt_camera cam;
@@ -403,7 +402,7 @@ Color Integrator::cast_ray(const Ray& ray, int recursions, int branches) {
     pt_render_stats st;
     scene->tree->lock_device(device);
     int rc = pt_cast_rays(ds, &cam, lights.data(), (int)lights.size(), 1, &o[0], &o[1], &o[2], &d[0], &d[1], &d[2], &id, 0,
-                          min(max(recursions, 0), 10), seed, rgb, &st);
+                          min(max(recursions, 0), 10), min(branches, PT_MAX_BRANCHES), seed, rgb, &st);
     scene->tree->unlock_device(device);
     if (rc != PT_OK) { cerr << "Integrator::cast_ray: " << pt_last_error() << endl; return Color(0, 0, 0); }
     __sync_fetch_and_add(&rays_cast, (long long)(st.closest_rays + st.shadow_rays));

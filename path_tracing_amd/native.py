@@ -144,7 +144,7 @@ def hip_lib():
         L.pt_films_reduce.argtypes = [vp, i32, vp, vp]
         L.pt_render_passes.argtypes = [vp, C.POINTER(Camera), vp, i32, vp, i32, u64, C.POINTER(RenderStats)]
         L.pt_camera_rays_dev.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, u32, u64] + [vp] * 6
-        L.pt_cast_rays.argtypes = [vp, C.POINTER(Camera), vp, i32, u64] + [vp] * 7 + [u32, i32, u64, vp, C.POINTER(RenderStats)]
+        L.pt_cast_rays.argtypes = [vp, C.POINTER(Camera), vp, i32, u64] + [vp] * 7 + [u32, i32, i32, u64, vp, C.POINTER(RenderStats)]
         L.pt_last_error.restype = C.c_char_p
         L.pt_build_info.restype = C.c_char_p
         _hip = L

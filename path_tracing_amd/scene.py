@@ -217,7 +217,7 @@ class GpuScene:
         check(getattr(native.hip_lib(), name)(
             self.h, n, *ptrs, C.c_void_p(dist.data_ptr()), C.c_void_p(out_vis.data_ptr())), name)
 
-    def cast_rays(self, cam: Camera, lights, origins, dirs, stream_ids=None, sample=0, recursions=10, seed=1):
+    def cast_rays(self, cam: Camera, lights, origins, dirs, stream_ids=None, sample=0, recursions=10, seed=1, branches=1):
         """Radiance along each given ray (Integrator::cast_ray); returns (rgb [n,3], RenderStats)."""
         o = _f32(origins).reshape(-1, 3)
         d = _f32(dirs).reshape(-1, 3)
@@ -228,7 +228,7 @@ class GpuScene:
         st = RenderStats()
         larr = make_lights(lights)
         check(native.hip_lib().pt_cast_rays(self.h, C.byref(cam), larr, len(lights), n, *[_p(c) for c in cols],
-                                            _p(ids) if ids is not None else None, sample, recursions, seed, _p(rgb), C.byref(st)),
+                                            _p(ids) if ids is not None else None, sample, recursions, branches, seed, _p(rgb), C.byref(st)),
               "pt_cast_rays")
         return rgb, st
 

@@ -189,4 +189,7 @@ def load_emul():
     vp = C.c_void_p
     E.emul_raycast_closest.argtypes = [vp, C.c_uint64] + [vp] * 7
     E.emul_raycast_shadow.argtypes = [vp, C.c_uint64] + [vp] * 4
+    E.emul_raycast_shadow_q.argtypes = [vp, C.c_uint64] + [vp] * 5
+    E.emul_raycast_occluded_q.argtypes = [vp, C.c_uint64] + [vp] * 4
+    E.emul_work_counts.argtypes = [vp, C.c_uint64, vp, vp]
     return E

