@@ -678,6 +678,10 @@ struct PathCtx {
     /* Added to the stream numbers of the bounce draws and of the light draws below the first hit:
      * 256 * k for sub-path k of a cast_ray call with several branches, 0 otherwise. */
     uint32_t stream_off = 0;
+    /* Product of the bounce weights down to the current path vertex, one binary32 product per bounce
+     * (1 at the first hit): what the GPU renderer multiplies a light sample's weight by.  Used only
+     * for the bookkeeping of shadow_weighted; the radiance is formed as the reference forms it. */
+    float throughput = 1.0f;
 };
 
 inline void capture_ray(PathCtx& ctx, const Ray& r, float dist, float tag) {
@@ -727,7 +731,10 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth, int branche
         }
         Ray scattered = make_ray(hit, scatter_direction);
         float w = (float)((1.0 / branches) * 0.8);
+        const float outer_throughput = ctx.throughput;
+        ctx.throughput = w * outer_throughput;
         energy = energy + w * cast_ray(ctx, scattered, recursions - 1, depth + 1, 1); /* :107 */
+        ctx.throughput = outer_throughput;
         ctx.stream_off = outer_off;
     }
     for (int l = 0; l < ctx.n_lights; l++) { /* :112-148 */
@@ -742,10 +749,9 @@ V3 cast_ray(PathCtx& ctx, const Ray& ray, int recursions, int depth, int branche
         Hit sh;
         ctx.shadow_casts++;
         float dist = norm(to_light);
-        {   /* the sample's weight as the GPU renderer forms it: throughput 0.8^depth (one binary32
-             * product per bounce) times colour / dist^2 * (lambert + phong^16) */
-            float thr = 1.0f;
-            for (int k = 0; k < depth; k++) thr = 0.8f * thr;
+        {   /* the sample's weight as the GPU renderer forms it: the path's throughput times
+             * colour / dist^2 * (lambert + phong^16) */
+            const float thr = ctx.throughput;
             V3 wgt = (lc / (dist * dist)) * (real_max(0.0f, dot(n, to_light) / dist) +
                                              square(square(square(square(real_max(0.0f, dot(reflection, to_light) / dist))))));
             const bool zero = thr * wgt.x == 0.0f && thr * wgt.y == 0.0f && thr * wgt.z == 0.0f;

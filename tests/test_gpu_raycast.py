@@ -323,12 +323,12 @@ def test_several_triangles_per_round_kernels(scene_small, scene_medium, monkeypa
 
 
 def test_any_hit_walks_with_and_without_quantised_nodes(scene_medium, monkeypatch):
-    """The any-hit kernels read interior nodes whose children are both interior as 32-byte quantised
-    records; PT_QNODES=0 makes a scene without them.  Same visibility bit for bit, for both shadow
-    tests, and the same film."""
+    """With PT_QNODES=1 the any-hit kernels read interior nodes whose children are both interior as
+    32-byte quantised records (an option: it saves load bytes and costs instructions).  Same visibility
+    bit for bit, for both shadow tests, and the same film."""
     sc = scene_medium
-    monkeypatch.setenv("PT_QNODES", "0")
-    plain = pta.GpuScene(sc.host, 0)
+    monkeypatch.setenv("PT_QNODES", "1")
+    plain = pta.GpuScene(sc.host, 0)       # "plain" in name only: this one walks q-nodes, sc.gpu does not
     monkeypatch.delenv("PT_QNODES")
     cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
     films = []
