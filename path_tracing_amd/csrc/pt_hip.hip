@@ -1153,13 +1153,17 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     const size_t tris_off = (nb + 255) & ~(size_t)255;
     if (tris_off + tb >= ((size_t)1 << 32)) return cleanup(fail(PT_ERR_LIMIT, "nodes and triangle records exceed 4 GiB"));
     /* Quantised interior nodes for the any-hit walks, behind the triangle records if they still fit
-     * below 4 GiB.  Off unless PT_QNODES=1: they halve the bytes of most node fetches, but the trace
-     * kernels are bound by vector instructions, not by their loads, and decoding costs instructions
-     * (measured on MI355X: the shadow launches of a 1080p render take 26 % longer with them). */
+     * below 4 GiB.  They halve the bytes of most node fetches and cost about 90 vector instructions
+     * per round to decode.  Where the geometry is served by the caches the trace kernels are bound by
+     * vector instructions, not by their loads, and lose (measured on MI355X, 1.34 M triangles: shadow
+     * launches 26 % slower); where it streams from HBM they win (21.5 M triangles: shadow launches
+     * 4 % faster).  So: only for geometry larger than the 256 MiB Infinity Cache.  PT_QNODES=0 / 1
+     * overrides. */
     ptq::QNodes qn;
     {
-        const char* e = getenv("PT_QNODES");
-        if (e && atoi(e) == 1) ptq::build_qnodes(flat, qn);
+        bool want = tris_off + tb > ((size_t)256 << 20);
+        if (const char* e = getenv("PT_QNODES")) want = atoi(e) == 1;
+        if (want) ptq::build_qnodes(flat, qn);
     }
     const size_t q_off = (tris_off + tb + 255) & ~(size_t)255;
     const size_t qb = qn.rec.size() * sizeof(ptq::QNodeRec);

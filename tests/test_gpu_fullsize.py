@@ -105,3 +105,33 @@ def test_full_frame_render(big):
     assert np.array_equal(got[rows].view(np.uint32), full[rows].view(np.uint32))   # a band is part of the frame
     err = np.abs(got - want)
     assert (err <= 1e-5 * np.maximum(np.abs(want), 1.0)).all(), err.max()
+
+
+def test_full_frame_lambert_band(big):
+    """The flagged Lambertian bounce mode (integrator.cpp:79-84 without :104, the README's "diffuse"
+    look) at the full size of the path-tracing configuration: an 8-row band of the 1920x1080 frame,
+    2 samples, against the oracle -- identical ray counts (bounce directions are bit-exact, so every
+    path meets the same triangles), radiance within the summation-order tolerance -- and a band
+    rendered alone equals the same rows of a full-frame render."""
+    tris, host, gpu = big
+    W, H, S = 1920, 1080, 2
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5, bounce_mode=1)
+    band = (0, 536, W, 8)
+    oracle = orc.Scene(tris, threads=16)
+    want, want_p, counts = oracle.render(orc.cli_camera(dof_aperture=0.1, dof_distance=4.5, bounce_mode=1), orc.cli_lights(), W, H,
+                                         band, 0, S, seed=9, threads=16)
+    film = pta.Film(gpu, W, H)
+    st = film.render(cam, pta.cli_lights(), [band + (0, S)], seed=9)
+    got, got_p = film.read()
+    assert np.array_equal(got_p, want_p)
+    assert (st.closest_rays, st.shadow_rays, st.shadow_rays_traced) == (int(counts[0]), int(counts[1]), int(counts[2]))
+    err = np.abs(got - want)
+    assert (err <= 1e-5 * np.maximum(np.abs(want), 1.0)).all(), err.max()
+    # diffuse paths live longer than mirror paths on this scene: more casts per camera sample
+    mirror = film.render(pta.cli_camera(dof_aperture=0.1, dof_distance=4.5), pta.cli_lights(), [band + (S, S)], seed=9)
+    assert st.closest_rays > mirror.closest_rays
+    film.zero()
+    film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=9)
+    full, _ = film.read()
+    rows = slice(536, 544)
+    assert np.array_equal(got[rows].view(np.uint32), full[rows].view(np.uint32))
