@@ -253,7 +253,7 @@ def main():
     reduce_to_rank0()  # untimed: first use of the collective (communicator, kernels)
     torch.cuda.synchronize()
     film.zero()
-    for c in range(5):
+    for c in range(6):
         gpu.kernel_time(c, reset=True)
     gpu.sync()
 
@@ -268,7 +268,7 @@ def main():
     barrier()
     elapsed = all_max(time.perf_counter() - t_start)
     closest_all, shadow_all, samples_all, traced_all = all_sum([tally.closest, tally.shadow, tally.samples, tally.traced])
-    kt = {c: gpu.kernel_time(c) for c in range(5)}
+    kt = {c: gpu.kernel_time(c) for c in range(6)}
     film_ok = None
     if rank == 0:
         # sanity of the reduced film: every pixel got every rank's passes
@@ -335,7 +335,7 @@ def main():
             "strong_scaling": strong_extra,
             "scene_prepare_s": round(t_prepare, 2),
             "kernel_ms": {name: {"ms": round(kt[c][0], 3), "launches": kt[c][1]} for c, name in
-                          enumerate(["closest", "shadow", "generate", "shade", "accumulate"])},
+                          enumerate(["closest", "shadow", "generate", "shade", "accumulate", "shadow_exact_pass"])},
         }
 
         # ---- CPU oracle: work per ray in reference visit order, and (N=1) the CPU baseline ----

@@ -171,13 +171,16 @@ int pt_scene_sync(pt_scene* s);
 
 /* Milliseconds the GPU spent in this scene's kernels of one class since the last call with
  * reset != 0, measured with HIP events on the scene's stream, and the number of launches.
- * Classes: 0 closest-hit, 1 shadow, 2 generate, 3 shade, 4 accumulate. */
+ * Classes: 0 closest-hit, 1 shadow (the any-hit walk that answers light samples at distance >= 1,
+ * or the bounded test), 2 generate, 3 shade, 4 accumulate, 5 the closest-hit pass for the shadow
+ * rays of nearer lights (one launch per depth, nearly always over an empty queue). */
 #define PT_KERNEL_CLOSEST    0
 #define PT_KERNEL_SHADOW     1
 #define PT_KERNEL_GENERATE   2
 #define PT_KERNEL_SHADE      3
 #define PT_KERNEL_ACCUMULATE 4
-#define PT_KERNEL_CLASSES    5
+#define PT_KERNEL_SHADOW_EXACT 5
+#define PT_KERNEL_CLASSES    6
 int pt_scene_kernel_time(pt_scene* s, int kernel_class, int reset, double* ms, uint64_t* launches);
 
 /* ---- film and rendering -------------------------------------------------------------- */

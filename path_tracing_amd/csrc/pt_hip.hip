@@ -1017,8 +1017,8 @@ struct pt_scene {
     bool use_qnodes = false;            /* the any-hit launches use the kernels that read quantised interior nodes */
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
-    uint64_t launches[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0};
+    double ms[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+    uint64_t launches[PT_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
     bool timing = true;
 };
 
@@ -1264,7 +1264,7 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     const LaunchCtx here = ctx ? *ctx : LaunchCtx{s->stream, s->d_spill};
     a.spill = here.spill;
     if (a.count_mul == 0) a.count_mul = 1;
-    ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : PT_KERNEL_SHADOW, here.stream);
+    ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : MODE == TRACE_SHADOW_EXACT ? PT_KERNEL_SHADOW_EXACT : PT_KERNEL_SHADOW, here.stream);
     constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
     const dim3 grid(trace_grid(s, ANY));
     if (ANY && s->use_qnodes) {

@@ -285,3 +285,124 @@ extern "C" void packet_model(const pt_flat_scene* sc, uint64_t n, const float* o
         out[4]++;
     }
 }
+
+/* Policy 6 (any-hit walks only): DEFERRED, DENSE triangle tests.  A lane that reaches a leaf does not
+ * test its triangles: it appends {lane, first triangle, count} to a FIFO of the wave and goes on
+ * walking at once (the any-hit answer does not depend on the order of the tests).  Whenever the
+ * FIFO holds at least 64 triangle tests -- or the wave has nothing else to do -- one DENSE pass
+ * tests the next 64 (or fewer) of them, one per lane whatever lane the ray belongs to; a hit marks
+ * the owner's ray, which stops at its next round.  `lag` rounds pass between taking tests off the
+ * FIFO and their results (the records are fetched a round ahead).  A ray is finished when its walk
+ * is over and none of its tests is outstanding.
+ * Costs: c_round per round (bookkeeping, pops, loads, enqueue), c_node per node section, c_tri per
+ * dense pass, c_start per refill.  out->lane_tri counts triangle tests, out->tri_sections dense passes. */
+#include <deque>
+#include <vector>
+extern "C" void wave_sim_deferred(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const SimParams* p, SimStats* out) {
+    CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
+    ptc::RootBox root;
+    root.mnx = sc->root_min[0]; root.mny = sc->root_min[1]; root.mnz = sc->root_min[2];
+    root.mxx = sc->root_max[0]; root.mxy = sc->root_max[1]; root.mxz = sc->root_max[2];
+    const bool scene_tame = ptc::root_is_tame(root);
+    static ptc::Lane L[64];
+    static CpuStack st[64];
+    bool active[64], found[64];
+    int outstanding[64];
+    for (int i = 0; i < 64; i++) { active[i] = false; found[i] = false; outstanding[i] = 0; }
+    struct Item { int lane; uint32_t tri; uint32_t count; };
+    std::deque<Item> fifo;
+    uint64_t queued_tests = 0;
+    struct Batch { std::vector<std::pair<int, uint32_t>> tests; int due; };
+    std::deque<Batch> in_flight;
+    const int lag = p->tri_threshold;   /* reused: rounds between taking tests and having their results */
+    uint64_t next = 0;
+    SimStats s;
+    memset(&s, 0, sizeof s);
+    int round = 0;
+    while (true) {
+        int idle = 0;
+        for (int i = 0; i < 64; i++) idle += !active[i];
+        int start_list[64], n_start = 0;
+        if (idle && next < n && (idle >= p->refill_min || idle == 64)) {
+            for (int i = 0; i < 64 && next < n; i++) if (!active[i]) start_list[n_start++] = i, next++;
+        }
+        if (next >= n && idle == 64 && n_start == 0) break;
+        round++;
+        s.rounds++;
+        s.cost += p->c_round;
+        /* results of batches that are due */
+        while (!in_flight.empty() && in_flight.front().due <= round) {
+            for (auto& t : in_flight.front().tests) {
+                ptc::TriData tr; mem.load_tri(t.second, tr);
+                float tt, uu, vv;
+                if (ptc::tri_hit(tr, L[t.first].r, tt, uu, vv)) found[t.first] = true;
+                outstanding[t.first]--;
+                s.lane_tri++;
+            }
+            in_flight.pop_front();
+        }
+        /* rays marked as hit stop walking */
+        for (int i = 0; i < 64; i++) if (active[i] && found[i]) { L[i].cur = PT_REF_NONE; L[i].sp = 0; }
+        /* node section */
+        bool some = false;
+        for (int i = 0; i < 64; i++) {
+            ptc::Lane& l = L[i];
+            if (!active[i] || !ptc::lane_has_node(l)) continue;
+            ptc::NodeData nd; mem.load_node(l.cur, nd);
+            if (l.tame) ptc::lane_node<true, true>(l, nd, st[i]); else ptc::lane_node<true, false>(l, nd, st[i]);
+            s.lane_node++; some = true;
+        }
+        if (some) { s.node_sections++; s.cost += p->c_node; }
+        /* leaves reached (by the step or by last round's pop) are queued, then one pop */
+        auto enqueue = [&](int i) {
+            ptc::Lane& l = L[i];
+            if (!ptc::lane_has_leaf(l)) return;
+            uint32_t pos = ptc::lane_leaf_pos(l);
+            uint32_t count = sc->tris[pos].leaf_remaining + 1u;
+            fifo.push_back({i, pos, count});
+            queued_tests += count; outstanding[i] += (int)count;
+            l.cur = PT_REF_NONE;
+        };
+        for (int i = 0; i < 64; i++) if (active[i]) enqueue(i);
+        for (int i = 0; i < 64; i++) {
+            ptc::Lane& l = L[i];
+            if (!active[i] || l.cur != PT_REF_NONE || l.sp <= 0) continue;
+            ptc::lane_pop<true>(l, st[i]);
+            s.lane_pop++;
+            enqueue(i);   /* a popped leaf is queued in the same round; the lane pops again next round */
+        }
+        /* dense pass: when 64 tests wait, or when no lane has a node to visit and tests remain */
+        bool walkers = false;
+        for (int i = 0; i < 64; i++) if (active[i] && (ptc::lane_has_node(L[i]) || L[i].sp > 0)) walkers = true;
+        if (queued_tests >= 64 || (queued_tests > 0 && (!walkers || (int)in_flight.size() == 0 && !walkers))) {
+            Batch b; b.due = round + lag;
+            int room = 64;
+            while (room > 0 && !fifo.empty()) {
+                Item& it = fifo.front();
+                uint32_t take = it.count < (uint32_t)room ? it.count : (uint32_t)room;
+                for (uint32_t k = 0; k < take; k++) b.tests.push_back({it.lane, it.tri + k});
+                it.tri += take; it.count -= take; room -= (int)take; queued_tests -= take;
+                if (it.count == 0) fifo.pop_front();
+            }
+            in_flight.push_back(b);
+            s.tri_sections++; s.cost += p->c_tri;
+        }
+        /* retire: walk over and nothing outstanding */
+        for (int i = 0; i < 64; i++)
+            if (active[i] && ptc::lane_finished(L[i]) && outstanding[i] == 0) active[i] = false;
+        if (n_start) {
+            s.start_sections++; s.cost += p->c_start;
+            for (int k = 0; k < n_start; k++) {
+                int i = start_list[k];
+                uint64_t r = next - n_start + k;
+                L[i].r.ox = o[3 * r]; L[i].r.oy = o[3 * r + 1]; L[i].r.oz = o[3 * r + 2];
+                L[i].r.dx = d[3 * r]; L[i].r.dy = d[3 * r + 1]; L[i].r.dz = d[3 * r + 2];
+                ptc::ray_set_recip(L[i].r);
+                ptc::lane_start(L[i], sc->root_ref, root, scene_tame);
+                found[i] = false; outstanding[i] = 0;
+                active[i] = !ptc::lane_finished(L[i]);
+            }
+        }
+    }
+    *out = s;
+}
