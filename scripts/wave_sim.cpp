@@ -298,6 +298,8 @@ extern "C" void packet_model(const pt_flat_scene* sc, uint64_t n, const float* o
  * dense pass, c_start per refill.  out->lane_tri counts triangle tests, out->tri_sections dense passes. */
 #include <deque>
 #include <vector>
+static uint8_t* g_deferred_vis = nullptr;   /* optional: per ray, 1 = no triangle hit (set with wave_sim_deferred_vis) */
+extern "C" void wave_sim_deferred_vis(uint8_t* vis) { g_deferred_vis = vis; }
 extern "C" void wave_sim_deferred(const pt_flat_scene* sc, uint64_t n, const float* o, const float* d, const SimParams* p, SimStats* out) {
     CpuMem mem; mem.nodes = sc->nodes; mem.tris = sc->tris;
     ptc::RootBox root;
@@ -308,6 +310,7 @@ extern "C" void wave_sim_deferred(const pt_flat_scene* sc, uint64_t n, const flo
     static CpuStack st[64];
     bool active[64], found[64];
     int outstanding[64];
+    uint64_t ray_of[64];
     for (int i = 0; i < 64; i++) { active[i] = false; found[i] = false; outstanding[i] = 0; }
     struct Item { int lane; uint32_t tri; uint32_t count; };
     std::deque<Item> fifo;
@@ -335,7 +338,8 @@ extern "C" void wave_sim_deferred(const pt_flat_scene* sc, uint64_t n, const flo
             for (auto& t : in_flight.front().tests) {
                 ptc::TriData tr; mem.load_tri(t.second, tr);
                 float tt, uu, vv;
-                if (ptc::tri_hit(tr, L[t.first].r, tt, uu, vv)) found[t.first] = true;
+                /* a hit counts if it is nearer than the best so far, which is +inf until the walk stops (kdtree.cpp:286) */
+                if (ptc::tri_hit(tr, L[t.first].r, tt, uu, vv) && tt < ptc::pt_inf()) found[t.first] = true;
                 outstanding[t.first]--;
                 s.lane_tri++;
             }
@@ -389,7 +393,10 @@ extern "C" void wave_sim_deferred(const pt_flat_scene* sc, uint64_t n, const flo
         }
         /* retire: walk over and nothing outstanding */
         for (int i = 0; i < 64; i++)
-            if (active[i] && ptc::lane_finished(L[i]) && outstanding[i] == 0) active[i] = false;
+            if (active[i] && ptc::lane_finished(L[i]) && outstanding[i] == 0) {
+                active[i] = false;
+                if (g_deferred_vis) g_deferred_vis[ray_of[i]] = found[i] ? 0 : 1;
+            }
         if (n_start) {
             s.start_sections++; s.cost += p->c_start;
             for (int k = 0; k < n_start; k++) {
@@ -399,8 +406,9 @@ extern "C" void wave_sim_deferred(const pt_flat_scene* sc, uint64_t n, const flo
                 L[i].r.dx = d[3 * r]; L[i].r.dy = d[3 * r + 1]; L[i].r.dz = d[3 * r + 2];
                 ptc::ray_set_recip(L[i].r);
                 ptc::lane_start(L[i], sc->root_ref, root, scene_tame);
-                found[i] = false; outstanding[i] = 0;
+                found[i] = false; outstanding[i] = 0; ray_of[i] = r;
                 active[i] = !ptc::lane_finished(L[i]);
+                if (!active[i] && g_deferred_vis) g_deferred_vis[r] = 1;   /* misses the root box */
             }
         }
     }

@@ -349,3 +349,27 @@ def test_any_hit_walks_with_and_without_quantised_nodes(scene_medium, monkeypatc
         want = sc.oracle.shadow_visible(o, d, bound, bounded=True)
         assert np.array_equal(sc.gpu.raycast_shadow(o, d, bound, bounded=True), want), name + " bounded"
         assert np.array_equal(plain.raycast_shadow(o, d, bound, bounded=True), want), name + " bounded"
+
+
+def test_deferred_dense_triangle_tests(scene_small, scene_medium, monkeypatch):
+    """PT_DENSE_SHADOW=1 answers the light-visibility test with k_shadow_dense: leaves are queued in
+    LDS instead of tested in place, and dense passes test the queued triangles four lanes per item,
+    whatever lane the ray lives in (an option: fewer instructions, but slower on MI355X).  Same
+    visibility bit for bit on every ray set, and the same film."""
+    monkeypatch.setenv("PT_DENSE_SHADOW", "1")
+    dense = {id(sc): pta.GpuScene(sc.host, 0) for sc in (scene_small, scene_medium)}
+    monkeypatch.delenv("PT_DENSE_SHADOW")
+    for sc in (scene_small, scene_medium):
+        g = dense[id(sc)]
+        for name, (o, d) in all_ray_sets(sc.tris, 20000).items():
+            rng = np.random.default_rng(23)
+            dist = np.where(rng.random(len(o)) < 0.3, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
+            assert np.array_equal(g.raycast_shadow(o, d, dist), sc.oracle.shadow_visible(o, d, dist)), name
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    films = []
+    for g in (scene_medium.gpu, dense[id(scene_medium)]):
+        f = pta.Film(g, 320, 200)
+        st = f.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 4)], seed=31)
+        films.append((f.read(), (st.closest_rays, st.shadow_rays, st.shadow_rays_traced)))
+    assert films[0][1] == films[1][1]
+    assert np.array_equal(films[0][0][0].view(np.uint32), films[1][0][0].view(np.uint32)) and np.array_equal(films[0][0][1], films[1][0][1])

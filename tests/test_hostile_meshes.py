@@ -90,10 +90,14 @@ def test_host_tree_and_lane_walk(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MESH_NAMES)
-def test_gpu_matches_oracle(name):
+@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW"])
+def test_gpu_matches_oracle(name, option, monkeypatch):
+    """option: the any-hit walks on quantised interior nodes, or with deferred dense triangle tests."""
     tris, scale = hostile_meshes()[name]
     host = pta.HostScene(tris)
     oracle = orc.Scene(tris)
+    if option:
+        monkeypatch.setenv(option, "1")
     gpu = pta.GpuScene(host, 0)
     some_hit = False
     for rname, (o, d) in ray_sets(tris, scale).items():
