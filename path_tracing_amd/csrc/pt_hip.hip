@@ -549,6 +549,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
 #ifndef DENSE_WAVES_PER_EU
 #define DENSE_WAVES_PER_EU 7   /* register budget: 72 */
 #endif
+#ifndef DENSE_WAVES_PER_EU_2
+#define DENSE_WAVES_PER_EU_2 5 /* two rays per lane: register budget 102 */
+#endif
+#ifndef DENSE_RAYS_PER_LANE
+#define DENSE_RAYS_PER_LANE 1   /* 2 was measured: 485-588 ms against 325 ms for the shadow launches of two bench steps */
+#endif
+#define DENSE_SPILL_ENTRIES (STACK_MAX_ANYHIT - DENSE_STACK_LDS)   /* per ray, beyond the LDS part */
 
 /* popcount of the bits of `mask` below this lane */
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
@@ -578,27 +585,41 @@ struct AnyStack {
     __device__ __forceinline__ void peek3(int, uint32_t&, uint32_t&, uint32_t&) const {}      /* closest-hit only */
 };
 
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DENSE_WAVES_PER_EU))) void k_shadow_dense(DScene sc, TraceArgs a) {
-    __shared__ uint32_t stk[DENSE_STACK_LDS * TRACE_BLOCK];
+/* NW = rays per lane (1 or 2).  With leaves deferred, every ray a lane holds is in the same phase
+ * (a node step, then a pop), so a lane can walk two rays without choosing between them: the node
+ * section simply runs once per ray.  That doubles the work a wave does per memory round trip,
+ * which the one-ray form lacks (it executes fewer instructions than k_trace but waits for its loads
+ * half of the time). */
+template <int NW>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(NW == 1 ? DENSE_WAVES_PER_EU : DENSE_WAVES_PER_EU_2))) void k_shadow_dense(DScene sc, TraceArgs a) {
+    constexpr uint32_t FIFO = NW == 1 ? DENSE_FIFO : 2u * DENSE_FIFO;
+    __shared__ uint32_t stk[NW * DENSE_STACK_LDS * TRACE_BLOCK];
     /* The FIFO carries values from one lane of a wave to another.  The lanes of a wave run in
      * lockstep and LDS serves a wave's accesses in order, so no barrier is needed -- but the compiler
      * reasons per thread, so every access is volatile. */
-    __shared__ uint64_t s_fifo[TRACE_BLOCK / 64][DENSE_FIFO];   /* {lane | count << 8, first triangle} */
+    __shared__ uint64_t s_fifo[TRACE_BLOCK / 64][FIFO];   /* {lane | ray-of-lane << 6 | count << 8, first triangle} */
     const uint32_t n = *a.d_count * a.count_mul;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = threadIdx.x >> 6;
-    AnyStack st;
-    st.lds = stk + threadIdx.x;
-    st.spill_base = a.spill;
+    AnyStack st[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) { st[w].lds = stk + w * DENSE_STACK_LDS * TRACE_BLOCK + threadIdx.x; st[w].spill_base = a.spill + (size_t)w * DENSE_SPILL_ENTRIES * gridDim.x * TRACE_BLOCK; }
     volatile uint64_t* const fifo = s_fifo[wid];
 
-    Lane L;
-    L.cur = PT_REF_NONE; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
-    L.best.t = 0.0f; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0u; L.best.mesh = 0u; L.local = 0.0f;
-    bool active = false;                  /* this lane holds a ray */
-    uint32_t out_index = 0;               /* where the ray's answer goes */
-    float dist = 0.0f;
-    uint32_t my_last = 0;                 /* number of the item after this ray's last one (0: none queued) */
+    Lane L[NW];
+    bool active[NW];                      /* the lane's w-th ray exists */
+    uint32_t out_index[NW];               /* where the ray's answer goes */
+    float dist[NW];
+    uint32_t my_last[NW];                 /* number of the item after this ray's last one (0: none queued) */
+    float4 q0[NW], q1[NW], q2[NW], q3[NW];   /* walker: the node record of this round */
+    bool rec_node[NW], starting[NW];
+    uint32_t new_ray[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        L[w].cur = PT_REF_NONE; L[w].sp = 0; L[w].found = false; L[w].frame_bits = 0; L[w].tame = true;
+        L[w].best.t = 0.0f; L[w].best.u = 0.0f; L[w].best.v = 0.0f; L[w].best.tri = 0u; L[w].best.mesh = 0u; L[w].local = 0.0f;
+        active[w] = false; out_index[w] = 0; dist[w] = 0.0f; my_last[w] = 0; rec_node[w] = false; starting[w] = false; new_ray[w] = 0;
+    }
     /* wave-uniform queue state: items are numbered from 0 as they are queued */
     uint32_t q_head = 0, q_tail = 0;      /* first item not yet handed out / next item number */
     uint32_t items_done = 0;              /* items whose tests have been carried out */
@@ -619,107 +640,124 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DEN
     const bool static_only = total_chunks <= (xcd_waves / TRACE_XCD_SUPER) * TRACE_XCD_SUPER * 8u;
     const bool scene_tame = root_is_tame(sc.root);
 
-    float4 q0, q1, q2, q3;                /* walker: the node record of this round */
     float4 t0, t1; float t2x = 0.0f;      /* tester: the triangle record of this round's test (nine floats) */
-    bool rec_node = false;
     bool test_valid = false;              /* this lane carries one test of the batch in flight */
-    uint32_t test_owner = lane;           /* lane whose ray the test belongs to */
-    bool starting = false;
-    uint32_t new_ray = 0;
+    uint32_t test_owner = lane;           /* lane (| ray-of-lane << 6) whose ray the test belongs to */
     uint32_t rounds = 0;
 
     while (true) {
         /* the round's single wait on global memory (see k_trace) */
-        asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
-                           "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            asm volatile("" :: "v"(q0[w].x), "v"(q0[w].y), "v"(q0[w].z), "v"(q0[w].w), "v"(q1[w].x), "v"(q1[w].y), "v"(q1[w].z), "v"(q1[w].w),
+                               "v"(q2[w].x), "v"(q2[w].y), "v"(q2[w].z), "v"(q2[w].w), "v"(q3[w].x), "v"(q3[w].y), "v"(q3[w].z));
+            asm volatile("" :: "v"(L[w].r.ox), "v"(L[w].r.oy), "v"(L[w].r.oz), "v"(L[w].r.dx), "v"(L[w].r.dy), "v"(L[w].r.dz), "v"(dist[w]), "v"(out_index[w]));
+        }
         asm volatile("" :: "v"(t0.x), "v"(t0.y), "v"(t0.z), "v"(t0.w), "v"(t1.x), "v"(t1.y), "v"(t1.z), "v"(t1.w), "v"(t2x));
-        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist), "v"(out_index));
         /* a mis-scheduled queue must not hang the GPU: no launch needs anywhere near this many rounds */
         if (++rounds > (1u << 22)) break;
 
-        /* ---- start the refilled lanes ---- */
-        bool defer = false;
-        if (starting) {
-            if (!(dist >= 1.0f)) defer = true;     /* nearer lights need the closest hit's v: the exact pass */
-            else {
-                ray_set_recip(L.r);
-                lane_start(L, sc.root_ref, sc.root, scene_tame);
-                active = true;
-                my_last = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            /* ---- start the refilled rays ---- */
+            bool defer = false;
+            if (starting[w]) {
+                if (!(dist[w] >= 1.0f)) defer = true;     /* nearer lights need the closest hit's v: the exact pass */
+                else {
+                    ray_set_recip(L[w].r);
+                    lane_start(L[w], sc.root_ref, sc.root, scene_tame);
+                    active[w] = true;
+                    my_last[w] = 0;
+                }
             }
-        }
-        {
             const uint64_t dm = __ballot(defer);
             if (dm) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(a.defer_count, (uint32_t)__popcll(dm));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (defer) a.defer_list[base + lanes_below(dm)] = new_ray;
+                if (defer) a.defer_list[base + lanes_below(dm)] = new_ray[w];
             }
-        }
 
-        /* ---- one node step per lane that has its record ---- */
-        {
+            /* ---- one node step per ray that has its record ---- */
             NodeData nd;
-            nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
-            nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
-            nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
-            if (__any(rec_node && !L.tame)) {
-                if (rec_node) lane_node<true, false>(L, nd, st);
+            nd.lo[0] = pt_f2{q0[w].x, q0[w].y}; nd.lo[1] = pt_f2{q0[w].z, q0[w].w}; nd.lo[2] = pt_f2{q1[w].x, q1[w].y};
+            nd.hi[0] = pt_f2{q1[w].z, q1[w].w}; nd.hi[1] = pt_f2{q2[w].x, q2[w].y}; nd.hi[2] = pt_f2{q2[w].z, q2[w].w};
+            nd.lo_ref = __float_as_uint(q3[w].x); nd.hi_ref = __float_as_uint(q3[w].y); nd.axis = __float_as_uint(q3[w].z);
+            if (__any(rec_node[w] && !L[w].tame)) {
+                if (rec_node[w]) lane_node<true, false>(L[w], nd, st[w]);
             } else {
-                if (rec_node) lane_node<true, true>(L, nd, st);
+                if (rec_node[w]) lane_node<true, true>(L[w], nd, st[w]);
             }
         }
 
-        /* ---- leaves are queued, not tested: up to two items of up to four triangles per round ---- */
+        /* ---- leaves are queued, not tested: up to two items of up to four triangles per ray and round ---- */
         {
-            const bool room = DENSE_FIFO - (q_tail - q_head) >= 128u;    /* wave-uniform; otherwise the lanes wait a round */
+            const bool room = FIFO - (q_tail - q_head) >= 128u * NW;     /* wave-uniform; otherwise the rays wait a round */
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const bool put = active && lane_has_leaf(L) && room;
-                const uint64_t pm = __ballot(put);
-                if (pm) {
-                    if (put) {
-                        const uint32_t left = ref_leaf_count(L.cur), take = left < 4u ? left : 4u;
-                        const uint32_t item = q_tail + lanes_below(pm);
-                        fifo[item & (DENSE_FIFO - 1u)] = (uint64_t)(lane | (take << 8)) | ((uint64_t)ref_leaf_start(L.cur) << 32);
-                        my_last = item + 1u;
-                        /* the rest of the leaf: same reference, four triangles further, four fewer */
-                        L.cur = left > 4u ? L.cur + 4u - (4u << PT_REF_COUNT_SHIFT) : PT_REF_NONE;
+            for (int w = 0; w < NW; w++) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const bool put = active[w] && lane_has_leaf(L[w]) && room;
+                    const uint64_t pm = __ballot(put);
+                    if (pm) {
+                        if (put) {
+                            const uint32_t left = ref_leaf_count(L[w].cur), take = left < 4u ? left : 4u;
+                            const uint32_t item = q_tail + lanes_below(pm);
+                            fifo[item & (FIFO - 1u)] = (uint64_t)(lane | ((uint32_t)w << 6) | (take << 8)) | ((uint64_t)ref_leaf_start(L[w].cur) << 32);
+                            my_last[w] = item + 1u;
+                            /* the rest of the leaf: same reference, four triangles further, four fewer */
+                            L[w].cur = left > 4u ? L[w].cur + 4u - (4u << PT_REF_COUNT_SHIFT) : PT_REF_NONE;
+                        }
+                        q_tail += (uint32_t)__popcll(pm);
                     }
-                    q_tail += (uint32_t)__popcll(pm);
                 }
             }
         }
 
-        /* ---- lanes with nowhere to go take their next position from the stack ---- */
-        if (active && L.cur == PT_REF_NONE && L.sp > 0) lane_pop<true>(L, st);
+        /* ---- rays with nowhere to go take their next position from the stack ---- */
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            if (active[w] && L[w].cur == PT_REF_NONE && L[w].sp > 0) lane_pop<true>(L[w], st[w]);
 
         /* ---- choose the next dense batch and start reading its items ---- */
-        const uint64_t idle = __ballot(!active);
         bool go = false;
         uint64_t item_word = 0;
         {
             const uint32_t n_items = q_tail - q_head;
-            const uint64_t walking = __ballot(active && (L.cur != PT_REF_NONE || L.sp > 0));
-            const uint64_t waiting = __ballot(active && L.cur == PT_REF_NONE && L.sp == 0);
-            /* a full pass, or lanes are waiting for results that only a pass brings: nobody walks any
-             * more, or so many lanes wait that the wave should refill */
-            go = n_items > 0u && (n_items >= 16u || walking == 0ull || (uint32_t)__popcll(waiting | idle) >= (uint32_t)DENSE_REFILL_MIN);
-            if (go && (lane >> 2) < n_items) item_word = fifo[(q_head + (lane >> 2)) & (DENSE_FIFO - 1u)];
+            uint32_t n_walking = 0, n_resting = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                n_walking += (uint32_t)__popcll(__ballot(active[w] && (L[w].cur != PT_REF_NONE || L[w].sp > 0)));
+                n_resting += (uint32_t)__popcll(__ballot(!active[w] || (L[w].cur == PT_REF_NONE && L[w].sp == 0)));
+            }
+            /* a full pass, or rays are waiting for results that only a pass brings: nobody walks any
+             * more, or so many rays wait (or are idle) that the wave should refill */
+            go = n_items > 0u && (n_items >= 16u || n_walking == 0u || n_resting >= (uint32_t)(DENSE_REFILL_MIN * NW));
+            if (go && (lane >> 2) < n_items) item_word = fifo[(q_head + (lane >> 2)) & (FIFO - 1u)];
         }
 
         /* ---- the dense triangle pass: one test per lane, for whichever ray it belongs to ---- */
         if (__any(test_valid)) {
             /* every lane takes part in the exchange (a lane without a test reads its own ray) */
-            const int src = (int)(test_owner << 2);
+            const int src = (int)((test_owner & 63u) << 2);
             Ray9 r;
-            r.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L.r.ox)));
-            r.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L.r.oy)));
-            r.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L.r.oz)));
-            r.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L.r.dx)));
-            r.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L.r.dy)));
-            r.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L.r.dz)));
+            r.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[0].r.ox)));
+            r.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[0].r.oy)));
+            r.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[0].r.oz)));
+            r.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[0].r.dx)));
+            r.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[0].r.dy)));
+            r.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[0].r.dz)));
+            if (NW > 1) {
+                const bool second = (test_owner & 64u) != 0u;
+                const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[NW - 1].r.ox)));
+                const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[NW - 1].r.oy)));
+                const float bz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[NW - 1].r.oz)));
+                const float cx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[NW - 1].r.dx)));
+                const float cy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[NW - 1].r.dy)));
+                const float cz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(L[NW - 1].r.dz)));
+                r.ox = second ? bx : r.ox; r.oy = second ? by : r.oy; r.oz = second ? bz : r.oz;
+                r.dx = second ? cx : r.dx; r.dy = second ? cy : r.dy; r.dz = second ? cz : r.dz;
+            }
             r.rx = 0.0f; r.ry = 0.0f; r.rz = 0.0f;   /* the triangle test does not use the reciprocals */
             bool hit = false;
             if (test_valid) {
@@ -732,23 +770,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DEN
                 /* a hit counts if it is nearer than the best so far (kdtree.cpp:286): +inf as long as the walk goes on */
                 hit = tri_hit(tr, r, tt, uu, vv) && tt < pt_inf();
             }
-            /* each hit goes to its owner lane, which stops walking (a pass has few hits) */
+            /* each hit goes to its owner, which stops walking (a pass has few hits) */
             uint64_t hm = __ballot(hit);
             while (hm) {
                 const int b = __builtin_ctzll(hm);
                 hm &= hm - 1ull;
                 const uint32_t owner = (uint32_t)__builtin_amdgcn_readlane((int)test_owner, b);
-                if (lane == owner) { L.found = true; L.cur = PT_REF_NONE; L.sp = 0; }
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    if (lane == (owner & 63u) && (owner >> 6) == (uint32_t)w) { L[w].found = true; L[w].cur = PT_REF_NONE; L[w].sp = 0; }
             }
             test_valid = false;
             items_done = done_after_batch;
         }
 
         /* ---- next round's node records ---- */
-        rec_node = active && lane_has_node(L);
-        if (rec_node) {
-            const float4* rec = (const float4*)(sc.geom + L.cur * (uint32_t)sizeof(pt_flat_node));
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            rec_node[w] = active[w] && lane_has_node(L[w]);
+            if (rec_node[w]) {
+                const float4* rec = (const float4*)(sc.geom + L[w].cur * (uint32_t)sizeof(pt_flat_node));
+                q0[w] = rec[0]; q1[w] = rec[1]; q2[w] = rec[2]; q3[w] = rec[3];
+            }
         }
 
         /* ---- the next batch's triangle records: four lanes per item ---- */
@@ -757,7 +800,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DEN
             const uint32_t taken = n_items < 16u ? n_items : 16u;
             const uint32_t w_lo = (uint32_t)item_word, w_hi = (uint32_t)(item_word >> 32);
             test_valid = (lane >> 2) < taken && (lane & 3u) < ((w_lo >> 8) & 7u);
-            test_owner = test_valid ? (w_lo & 63u) : lane;
+            test_owner = test_valid ? (w_lo & 127u) : lane;
             if (test_valid) {
                 const uint32_t tri = w_hi + (lane & 3u);
                 const float4* rec = (const float4*)(sc.geom + sc.tris_off + tri * (uint32_t)sizeof(pt_tri_isect));
@@ -768,17 +811,23 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DEN
         }
 
         /* ---- retire: the walk is over and every queued item of the ray has been tested ---- */
-        if (active && L.cur == PT_REF_NONE && L.sp == 0 && my_last <= items_done) {
-            a.vis[out_index] = L.found ? 0 : 1;
-            active = false;
+        uint64_t idle_mask[NW];
+        uint32_t n_idle = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (active[w] && L[w].cur == PT_REF_NONE && L[w].sp == 0 && my_last[w] <= items_done) {
+                a.vis[out_index[w]] = L[w].found ? 0 : 1;
+                active[w] = false;
+            }
+            idle_mask[w] = __ballot(!active[w]);
+            n_idle += (uint32_t)__popcll(idle_mask[w]);
+            starting[w] = false;
         }
 
-        /* ---- refill idle lanes (as k_trace) ---- */
-        const uint64_t idle_now = __ballot(!active);
-        starting = false;
-        if (idle_now) {
-            const uint32_t n_idle = (uint32_t)__popcll(idle_now);
-            if (!exhausted && (n_idle >= DENSE_REFILL_MIN || idle_now == ~0ull)) {
+        /* ---- refill idle ray slots (as k_trace) ---- */
+        if (n_idle) {
+            const bool all_idle = n_idle == 64u * NW;
+            if (!exhausted && (n_idle >= (uint32_t)(DENSE_REFILL_MIN * NW) || all_idle)) {
                 if (pool_next >= pool_end) {
                     uint32_t c = total_chunks;
                     if (first_chunk) {
@@ -804,19 +853,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DEN
                     }
                 }
                 if (!exhausted) {
-                    uint32_t k = pool_next + lanes_below(idle_now);
-                    starting = !active && (k < pool_end);
-                    new_ray = k;
+                    uint32_t before = 0;     /* idle slots of the rays-of-lane already served */
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const uint32_t k = pool_next + before + lanes_below(idle_mask[w]);
+                        starting[w] = !active[w] && (k < pool_end);
+                        new_ray[w] = k;
+                        before += (uint32_t)__popcll(idle_mask[w]);
+                    }
                     pool_next = min(pool_end, pool_next + n_idle);
                 }
             }
-            if (exhausted && idle_now == ~0ull) break;
+            if (exhausted && all_idle) break;
         }
-        if (starting) {
-            dist = a.dist[new_ray];
-            out_index = a.target ? a.target[new_ray] : new_ray;
-            L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
-            L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (starting[w]) {
+                const uint32_t i = new_ray[w];
+                dist[w] = a.dist[i];
+                out_index[w] = a.target ? a.target[i] : i;
+                L[w].r.ox = a.rays.ox[i]; L[w].r.oy = a.rays.oy[i]; L[w].r.oz = a.rays.oz[i];
+                L[w].r.dx = a.rays.dx[i]; L[w].r.dy = a.rays.dy[i]; L[w].r.dz = a.rays.dz[i];
+            }
         }
     }
 }
@@ -1587,7 +1645,7 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
     const dim3 grid(trace_grid(s, ANY));
     if (MODE == TRACE_SHADOW_ANY && s->use_dense) {
-        hipLaunchKernelGGL(k_shadow_dense, dim3(s->grid_dense), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+        hipLaunchKernelGGL(k_shadow_dense<DENSE_RAYS_PER_LANE>, dim3(s->grid_dense), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     }
     else if (ANY && s->use_qnodes) {
         constexpr int QMODE = ANY ? MODE : TRACE_SHADOW_ANY;   /* (keeps the closest-hit instantiations of this function valid) */
@@ -1623,7 +1681,7 @@ static int init_trace_launch(pt_scene* s) {
     }
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) { per_cu_c = v; per_cu_a = v; } }
     int per_cu_d = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_shadow_dense, TRACE_BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_shadow_dense<DENSE_RAYS_PER_LANE>, TRACE_BLOCK, 0));
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_d = v; }
     per_cu_d = std::max(1, std::min(per_cu_d, 8));
     s->grid_dense = std::max(8, (s->num_cus * per_cu_d) & ~7);
