@@ -118,9 +118,6 @@ PT_HD float det_erfinvf(float x) {
  * one of 2^23 cell midpoints x = (j + 0.5) / 2^23 in (0, 1) (exact in binary32, never 0 or 1),
  * and the variate is sqrt(2) * erfinv(+-x). */
 PT_HD float normal_from_word(uint32_t w) {
-#ifdef PT_EXPERIMENT_CHEAP_NORMAL   /* timing experiment only: NOT a normal variate */
-    return (float)(int32_t)w * (1.7f / 2147483648.0f);
-#endif
     float x = ((float)((w >> 8) & 0x7fffffu) + 0.5f) * (1.0f / 8388608.0f);
     if (w & 0x80000000u) x = -x;
     return 1.41421354f * det_erfinvf(x);
