@@ -22,6 +22,13 @@ typedef struct pth_scene pth_scene;
  * Returns NULL on an unreadable or malformed file (the reference prints "Couldn't read
  * input file." and carries on with an unusable Scene, integrator.cpp:23-26). */
 pth_scene* pth_scene_from_stl(const char* path, int threads);
+/* The same, and `mesh_ready(scene, ctx)` is called once, on a thread of the library's, as soon as
+ * the per-triangle data (pth_triangle_data, pth_num_triangles) is final -- while the tree is still
+ * being built -- so that a caller can fill its own mesh structures beside the build.  The call has
+ * returned before pth_scene_from_stl_with does.  No other function may be used on the scene from
+ * inside the callback. */
+typedef void (*pth_mesh_ready_fn)(const pth_scene* scene, void* ctx);
+pth_scene* pth_scene_from_stl_with(const char* path, int threads, pth_mesh_ready_fn mesh_ready, void* ctx);
 /* Same from n triangles of 9 floats (p0 p1 p2). */
 pth_scene* pth_scene_from_triangles(const float* verts, int64_t n, int threads);
 void       pth_scene_destroy(pth_scene* s);
@@ -35,6 +42,9 @@ void pth_timings(const pth_scene* s, double out[3]);
 /* Per-triangle data in mesh order, 30 floats each: p0 p1 p2 edge01 edge02 normal base_normal
  * u_normal v_normal plane 0 0 (Triangle, reference utils.h:94-113). */
 void pth_triangle_data(const pth_scene* s, float* out30);
+/* The same for triangles [first, last) only, on the calling thread: out30 receives
+ * (last - first) * 30 floats. */
+void pth_triangle_data_range(const pth_scene* s, int64_t first, int64_t last, float* out30);
 
 /* stats[0]=nodes, [1]=leaves, [2]=max depth, [3]=largest leaf, [4]=sum of leaf sizes. */
 void pth_tree_stats(const pth_scene* s, int64_t stats[5]);

@@ -112,6 +112,7 @@ class kdTree { /* kdtree.h:64-85 */
     pth_scene* built;                 /* mesh, tree and flattened arrays on the host */
     std::vector<pt_scene*> on_device; /* uploaded lazily, one per GPU */
     std::vector<pthread_mutex_t*> device_mutex; /* one per uploaded scene: a pt_scene is driven by one thread at a time */
+    std::vector<pthread_mutex_t*> upload_mutex; /* one per GPU: held while its scene is being created, so GPUs upload side by side */
     pthread_mutex_t lock;
     kdTree(std::vector<Triangle>* all_triangles, pth_scene* prebuilt); /* adopts a finished build */
     void lock_device(int device);

@@ -14,6 +14,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,25 +72,30 @@ static Vec vec3(const float* p) { return Vec(p[0], p[1], p[2]); }
 /* Triangle fields as the reference's constructor and set_normals leave them. */
 static void fill_triangles(const pth_scene* built, vector<Triangle>& tris) {
     int64_t n = pth_num_triangles(built);
-    vector<float> data((size_t)n * 30);
-    pth_triangle_data(built, data.data());
     tris.resize((size_t)n);
-    /* 156 bytes per triangle to fill: a handful of threads, each its own slice */
+    /* 156 bytes per triangle to fill: a handful of threads, each its own slice, a block at a time */
     const int n_threads = (int)max<int64_t>(1, min<int64_t>(8, n / 65536));
     vector<thread> pool;
     for (int w = 0; w < n_threads; w++)
         pool.emplace_back([&, w]() {
-            for (int64_t i = n * w / n_threads; i < n * (w + 1) / n_threads; i++) {
-                const float* d = &data[(size_t)i * 30];
-                Triangle& t = tris[(size_t)i];
-                for (int k = 0; k < 3; k++) t.points[k] = vec3(d + 3 * k);
-                t.edge01 = vec3(d + 9); t.edge02 = vec3(d + 12); t.normal = vec3(d + 15);
-                t.base_normal = vec3(d + 18); t.u_normal = vec3(d + 21); t.v_normal = vec3(d + 24);
-                for (int a = 0; a < 3; a++) {
-                    t.aabb.minima(a) = real_min(real_min(t.points[0](a), t.points[1](a)), t.points[2](a));
-                    t.aabb.maxima(a) = real_max(real_max(t.points[0](a), t.points[1](a)), t.points[2](a));
+            const int64_t block = 4096;
+            vector<float> data((size_t)block * 30);
+            const int64_t end = n * (w + 1) / n_threads;
+            for (int64_t at = n * w / n_threads; at < end; at += block) {
+                const int64_t m = min(block, end - at);
+                pth_triangle_data_range(built, at, at + m, data.data());
+                for (int64_t i = 0; i < m; i++) {
+                    const float* d = &data[(size_t)i * 30];
+                    Triangle& t = tris[(size_t)(at + i)];
+                    for (int k = 0; k < 3; k++) t.points[k] = vec3(d + 3 * k);
+                    t.edge01 = vec3(d + 9); t.edge02 = vec3(d + 12); t.normal = vec3(d + 15);
+                    t.base_normal = vec3(d + 18); t.u_normal = vec3(d + 21); t.v_normal = vec3(d + 24);
+                    for (int a = 0; a < 3; a++) {
+                        t.aabb.minima(a) = real_min(real_min(t.points[0](a), t.points[1](a)), t.points[2](a));
+                        t.aabb.maxima(a) = real_max(real_max(t.points[0](a), t.points[1](a)), t.points[2](a));
+                    }
+                    t.assigned_normal = t.normal;
                 }
-                t.assigned_normal = t.normal;
             }
         });
     for (thread& th : pool) th.join();
@@ -127,6 +133,7 @@ kdTree::kdTree(vector<Triangle>* _all_triangles, pth_scene* prebuilt) : all_tria
 kdTree::~kdTree() {
     for (pt_scene* s : on_device) pt_scene_destroy(s);
     for (pthread_mutex_t* m : device_mutex) if (m) { pthread_mutex_destroy(m); delete m; }
+    for (pthread_mutex_t* m : upload_mutex) if (m) { pthread_mutex_destroy(m); delete m; }
     if (built) pth_scene_destroy(built);
     delete root;
     pthread_mutex_destroy(&lock);
@@ -135,14 +142,30 @@ kdTree::~kdTree() {
 pt_scene* kdTree::device_scene(int device) {
     if (!built || device < 0) return nullptr;
     pthread_mutex_lock(&lock);
-    if ((int)on_device.size() <= device) { on_device.resize((size_t)device + 1, nullptr); device_mutex.resize((size_t)device + 1, nullptr); }
+    if ((int)on_device.size() <= device) {
+        on_device.resize((size_t)device + 1, nullptr);
+        device_mutex.resize((size_t)device + 1, nullptr);
+        upload_mutex.resize((size_t)device + 1, nullptr);
+    }
     if (!device_mutex[(size_t)device]) { device_mutex[(size_t)device] = new pthread_mutex_t; pthread_mutex_init(device_mutex[(size_t)device], NULL); }
+    if (!upload_mutex[(size_t)device]) { upload_mutex[(size_t)device] = new pthread_mutex_t; pthread_mutex_init(upload_mutex[(size_t)device], NULL); }
     pt_scene* s = on_device[(size_t)device];
+    pthread_mutex_t* creating = upload_mutex[(size_t)device];
+    pthread_mutex_unlock(&lock);
+    if (s) return s;
+    /* created outside the tree's lock (other GPUs' scenes, and calls that only look one up, go on
+     * meanwhile); the GPU's own upload lock makes it happen once */
+    pthread_mutex_lock(creating);
+    pthread_mutex_lock(&lock);
+    s = on_device[(size_t)device];
+    pthread_mutex_unlock(&lock);
     if (!s) {
         if (pt_scene_create(device, pth_flat_scene(built), &s) != PT_OK) s = nullptr;
+        pthread_mutex_lock(&lock);
         on_device[(size_t)device] = s;
+        pthread_mutex_unlock(&lock);
     }
-    pthread_mutex_unlock(&lock);
+    pthread_mutex_unlock(creating);
     return s;
 }
 
@@ -193,24 +216,27 @@ Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integr
         for (int i = 0; i < n; i++) (void)pt_device_prepare(i);
         return nullptr;
     }, nullptr) == 0;
-    pth_scene* built = pth_scene_from_stl(path.c_str(), 0);
+    /* the host-side mesh is filled in beside the tree build, as soon as the vertex normals exist */
+    mesh = new vector<Triangle>();
+    pth_scene* built = pth_scene_from_stl_with(path.c_str(), 0, [](const pth_scene* ready, void* into) { fill_triangles(ready, *(vector<Triangle>*)into); }, mesh);
     if (warming) pthread_join(warm, nullptr);
     if (built == nullptr) {
         cout << "Couldn't read input file." << endl;
+        delete mesh;
+        mesh = nullptr;
         return;
     }
-    mesh = new vector<Triangle>();
-    /* adopt the already built tree instead of building it a second time from the points; its flat
-     * arrays go up to the GPUs on a spare thread while this one fills in the host-side mesh */
+    /* adopt the already built tree instead of building it a second time from the points, and send
+     * its flat arrays up to the GPUs */
     tree = new kdTree(mesh, built);
-    pthread_t upload;
-    bool uploading = pthread_create(&upload, nullptr, [](void* t) -> void* {
-        int n = get_optimal_thread_count();
-        for (int i = 0; i < n; i++) (void)((kdTree*)t)->device_scene(i);
-        return nullptr;
-    }, tree) == 0;
-    fill_triangles(built, *mesh);
-    if (uploading) pthread_join(upload, nullptr);
+    const auto t0 = chrono::steady_clock::now();
+    {   /* one thread per GPU */
+        vector<thread> up;
+        kdTree* t = tree;
+        for (int i = 0, n = get_optimal_thread_count(); i < n; i++) up.emplace_back([t, i]() { (void)t->device_scene(i); });
+        for (thread& th : up) th.join();
+    }
+    if (getenv("PT_BUILD_TIMING")) fprintf(stderr, "[scene] upload %.2f s\n", chrono::duration<double>(chrono::steady_clock::now() - t0).count());
     cout << "Read in " << mesh->size() << " triangles." << endl;
     lights = new vector<Light>();
 }

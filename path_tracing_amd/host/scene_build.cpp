@@ -24,10 +24,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <unordered_map>
 #include <vector>
+
+#include <unistd.h>
 
 namespace {
 
@@ -111,15 +115,29 @@ inline VKey vkey(F3 p) { VKey k; k.a = fbits(p.x); k.b = fbits(p.y); k.c = fbits
 /* compute_barycentric_normals (reference stlreader.cpp:62-81): a corner's normal is the
  * normalised sum, taken in mesh order, of the face normals of all corners at the same
  * position.  Hash tables of vertex positions replace the reference's ordered map.  Each thread
- * owns the positions whose hash falls in its share, scans all corners in mesh order and sums
- * only its own, so every running sum visits its contributions in the same order as the
- * reference's per-vertex list whatever the thread count. */
+ * owns the positions whose hash falls in its share (hashes and owners are computed once, in
+ * parallel), scans the owners of all corners in mesh order and sums only its own, so every
+ * running sum visits its contributions in the same order as the reference's per-vertex list
+ * whatever the thread count. */
 void vertex_normals(Mesh& m, int threads) {
     const int64_t n = m.n;
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(threads, 64), n / 16384));
     std::vector<int32_t> corner((size_t)n * 3); /* index into the owner's sums */
     std::vector<uint8_t> owner((size_t)n * 3);
+    std::vector<uint32_t> hash_low((size_t)n * 3);
     std::vector<std::vector<F3>> sums((size_t)T);
+    parallel_ranges(n, threads, [&](int64_t first, int64_t last) {
+        VKeyHash hasher;
+        for (int64_t i = first; i < last; i++) {
+            const F3 c[3] = {m.p0[i], m.p1[i], m.p2[i]};
+            for (int k = 0; k < 3; k++) {
+                const uint64_t h = (uint64_t)hasher(vkey(c[k]));
+                owner[(size_t)(3 * i + k)] = (uint8_t)(((h >> 32) * (uint64_t)T) >> 32);
+                hash_low[(size_t)(3 * i + k)] = (uint32_t)h;
+            }
+        }
+    });
+    const double tn0 = now_s();
     auto job = [&](int me) {
         std::vector<F3>& sum = sums[(size_t)me];
         std::vector<VKey> keys;
@@ -128,12 +146,13 @@ void vertex_normals(Mesh& m, int threads) {
         std::vector<int32_t> slot(cap, -1);
         VKeyHash hasher;
         for (int64_t i = 0; i < n; i++) {
+            const uint8_t* own = &owner[(size_t)(3 * i)];
+            if (own[0] != me && own[1] != me && own[2] != me) continue;
             const F3 c[3] = {m.p0[i], m.p1[i], m.p2[i]};
             for (int k = 0; k < 3; k++) {
+                if (own[k] != me) continue;
                 const VKey key = vkey(c[k]);
-                const uint64_t h = (uint64_t)hasher(key);
-                if ((int)(((h >> 32) * (uint64_t)T) >> 32) != me) continue;
-                size_t at = (size_t)h & (cap - 1);
+                size_t at = (size_t)hash_low[(size_t)(3 * i + k)] & (cap - 1);
                 int32_t id;
                 while ((id = slot[at]) >= 0 && !(keys[(size_t)id] == key)) at = (at + 1) & (cap - 1);
                 if (id < 0) {
@@ -152,7 +171,6 @@ void vertex_normals(Mesh& m, int threads) {
                     }
                 }
                 corner[(size_t)(3 * i + k)] = id;
-                owner[(size_t)(3 * i + k)] = (uint8_t)me;
                 sum[(size_t)id] = add(sum[(size_t)id], m.normal[i]);
             }
         }
@@ -164,6 +182,8 @@ void vertex_normals(Mesh& m, int threads) {
         for (int t = 0; t < T; t++) pool.emplace_back(job, t);
         for (auto& th : pool) th.join();
     }
+    const double tn1 = now_s();
+    if (getenv("PT_BUILD_TIMING")) fprintf(stderr, "[normals] tables %.2f s (T=%d)\n", tn1 - tn0, T);
     m.vn0.resize(n); m.vn1.resize(n); m.vn2.resize(n);
     parallel_ranges(n, threads, [&](int64_t first, int64_t last) {
         for (int64_t i = first; i < last; i++) {
@@ -177,26 +197,148 @@ void vertex_normals(Mesh& m, int threads) {
 
 /* read_stl (reference stlreader.cpp:10-43): binary only, 80-byte header ignored, file
  * normals ignored, attribute byte count must be zero. */
-bool load_stl(const char* path, std::vector<float>& soup) {
+bool load_stl(const char* path, std::vector<float>& soup, int threads) {
     FILE* fp = fopen(path, "rb");
     if (!fp) return false;
     char header[80];
     uint32_t count = 0;
     bool ok = fread(header, 80, 1, fp) == 1 && fread(&count, 4, 1, fp) == 1;
-    if (ok) {
-        std::vector<unsigned char> buf((size_t)count * 50);
-        ok = count == 0 || fread(buf.data(), 50, count, fp) == count;
-        if (ok) {
-            soup.resize((size_t)count * 9);
-            for (uint32_t i = 0; i < count && ok; i++) {
-                memcpy(&soup[(size_t)i * 9], &buf[(size_t)i * 50 + 12], 36);
-                uint16_t attr; memcpy(&attr, &buf[(size_t)i * 50 + 48], 2);
-                if (attr != 0) ok = false;
+    if (ok && count > 0) {
+        /* the records are read in pieces, every thread its own range of the file */
+        const int fd = fileno(fp);
+        soup.resize((size_t)count * 9);
+        std::atomic<bool> good(true);
+        parallel_ranges((int64_t)count, threads, [&](int64_t first, int64_t last) {
+            const int64_t piece = 1 << 15; /* records per read */
+            std::vector<unsigned char> buf((size_t)piece * 50);
+            for (int64_t at = first; at < last && good; at += piece) {
+                const int64_t m = std::min(piece, last - at);
+                size_t got = 0;
+                while (got < (size_t)m * 50) {
+                    const ssize_t r = pread(fd, buf.data() + got, (size_t)m * 50 - got, (off_t)(84 + at * 50 + (int64_t)got));
+                    if (r <= 0) { good = false; return; }
+                    got += (size_t)r;
+                }
+                for (int64_t i = 0; i < m; i++) {
+                    memcpy(&soup[(size_t)(at + i) * 9], &buf[(size_t)i * 50 + 12], 36);
+                    uint16_t attr; memcpy(&attr, &buf[(size_t)i * 50 + 48], 2);
+                    if (attr != 0) good = false;
+                }
             }
-        }
+        });
+        ok = good;
     }
     fclose(fp);
     return ok;
+}
+
+/* ------------------------------------------------------- std::sort, in parallel */
+
+/*
+ * The leaf order of the reference's tree depends on where std::sort leaves equal keys
+ * (kdtree.cpp:479-494), so the lists must come out exactly as libstdc++'s std::sort leaves them.
+ * That algorithm is: quicksort steps (pivot = median of the second, middle and last element, swapped
+ * to the front; unguarded Hoare partition of the rest) on every range longer than 16, recursing on
+ * the right part and looping on the left, with a heap sort of a range whose depth budget
+ * (2 * floor(log2 n)) is used up; then one insertion sort over everything.  Two facts make it
+ * parallel without changing a single move:
+ *   - after a partition step the two parts never exchange elements again (nothing in the right part
+ *     compares less than anything in the left part, and insertion moves an element only past larger
+ *     ones), so they can be finished by different threads;
+ *   - the closing insertion sort is stable and therefore has one possible result per range, whichever
+ *     form of insertion sort produces it and however the array is cut at partition boundaries.
+ * keyed_sort() below restates the quicksort steps comparison for comparison and hands right parts of
+ * at least `spawn_min` elements to new threads.  Its moves depend on the library's algorithm, so it is
+ * checked once per process against std::sort itself on a tie-heavy array (keyed_sort_matches_std);
+ * if the two ever differ, std::sort is used.
+ */
+struct Keyed { float key; int32_t index; };
+inline bool key_less(const Keyed& a, const Keyed& b) { return a.key < b.key; }
+
+inline Keyed* partition_step(Keyed* first, Keyed* last) {
+    Keyed* mid = first + (last - first) / 2;
+    Keyed *a = first + 1, *b = mid, *c = last - 1;
+    if (key_less(*a, *b)) {
+        if (key_less(*b, *c)) std::swap(*first, *b);
+        else if (key_less(*a, *c)) std::swap(*first, *c);
+        else std::swap(*first, *a);
+    } else if (key_less(*a, *c)) std::swap(*first, *a);
+    else if (key_less(*b, *c)) std::swap(*first, *c);
+    else std::swap(*first, *b);
+    Keyed* lo = first + 1;
+    Keyed* hi = last;
+    const Keyed* pivot = first;
+    while (true) {
+        while (key_less(*lo, *pivot)) ++lo;
+        --hi;
+        while (key_less(*pivot, *hi)) --hi;
+        if (!(lo < hi)) return lo;
+        std::swap(*lo, *hi);
+        ++lo;
+    }
+}
+
+void quick_steps(Keyed* first, Keyed* last, int depth) {
+    while (last - first > 16) {
+        if (depth == 0) { std::partial_sort(first, last, last, key_less); return; }
+        --depth;
+        Keyed* cut = partition_step(first, last);
+        quick_steps(cut, last, depth);
+        last = cut;
+    }
+}
+
+inline void insertion_pass(Keyed* first, Keyed* last) {
+    for (Keyed* i = first + 1; i < last; ++i) {
+        const Keyed v = *i;
+        Keyed* j = i;
+        while (j > first && key_less(v, *(j - 1))) { *j = *(j - 1); --j; }
+        *j = v;
+    }
+}
+
+void keyed_sort_range(Keyed* first, Keyed* last, int depth, int64_t spawn_min) {
+    std::vector<std::thread> kids;
+    std::vector<std::pair<Keyed*, Keyed*>> mine;   /* ranges this thread finishes itself */
+    while (last - first > 16) {
+        if (depth == 0) { std::partial_sort(first, last, last, key_less); break; }
+        --depth;
+        Keyed* cut = partition_step(first, last);
+        if (last - cut >= spawn_min) kids.emplace_back(keyed_sort_range, cut, last, depth, spawn_min);
+        else { quick_steps(cut, last, depth); mine.emplace_back(cut, last); }
+        last = cut;
+    }
+    mine.emplace_back(first, last);
+    for (auto& r : mine) insertion_pass(r.first, r.second);
+    for (auto& t : kids) t.join();
+}
+
+int floor_log2(int64_t n) { int k = 0; while (n > 1) { n >>= 1; k++; } return k; }
+
+void keyed_sort(Keyed* first, Keyed* last, int64_t spawn_min) {
+    if (last - first > 1) keyed_sort_range(first, last, 2 * floor_log2(last - first), std::max<int64_t>(spawn_min, 64));
+}
+
+bool keyed_sort_matches_std() {
+    static const bool same = []() {
+        const int n = 300000;
+        std::vector<Keyed> a((size_t)n), b;
+        uint32_t x = 12345u;
+        for (int i = 0; i < n; i++) {
+            x = x * 1664525u + 1013904223u;
+            const uint32_t r = x >> 8;
+            /* a third distinct keys, a third from 64 values, a third from 3 values, some signed zeros */
+            float k = (i % 3 == 0) ? (float)r : (i % 3 == 1) ? (float)(r & 63u) : (float)(r % 3u);
+            if ((r & 1023u) == 7u) k = -0.0f;
+            a[(size_t)i].key = k; a[(size_t)i].index = i;
+        }
+        b = a;
+        std::sort(a.begin(), a.end(), key_less);
+        keyed_sort(b.data(), b.data() + n, 4096);
+        for (int i = 0; i < n; i++) if (a[(size_t)i].index != b[(size_t)i].index) return false;
+        return true;
+    }();
+    return same;
 }
 
 /* ------------------------------------------------------------------ builder */
@@ -219,8 +361,18 @@ struct Builder {
     const Mesh* m;
     std::vector<int32_t> lists[2][3]; /* [0]=by minimum, [1]=by maximum; per axis */
     std::vector<float> vals[2][3];    /* the coordinate each list is sorted by, in list order */
-    std::vector<uint8_t> low_side;    /* per triangle, scratch of the node that owns it */
-    std::vector<int32_t> rank_x;      /* per triangle: its place in the owning node's by-min-x segment */
+    std::vector<uint8_t> flags;       /* per triangle, scratch of the node that owns it: SIDE_LOW, CANDIDATE */
+    std::vector<int32_t> rank_x;      /* per split candidate: its place in the owning node's by-min-x segment */
+    /* Inside the builder a triangle goes by its place in an ordering of the mesh by grid cell (64^3
+     * cells over the mesh's box, cells in Morton order): the lists hold those numbers and the
+     * per-triangle scratch is indexed by them, so that the triangles of a node, which are neighbours
+     * in space, are neighbours in memory as well (a node's passes read per-triangle bytes in list
+     * order, i.e. at random).  The numbering changes no decision: the lists are sorted with the mesh's
+     * own indices and translated afterwards. */
+    std::vector<int32_t> orig;        /* mesh index of a builder number */
+    bool plain = true;                /* no NaN among the box coordinates: every segment of a list is sorted by its
+                                         value array, which the shortcuts below rely on */
+    enum : uint8_t { SIDE_LOW = 1, CANDIDATE = 2 };
     int spawn_depth = 0;
     int wide_threads = 1;
 
@@ -235,19 +387,21 @@ struct Builder {
      * searches); "first in list order" becomes "smallest place in the by-min-x list among equal
      * scores".  The binary searches never inspect element 0, which is harmless: s is the
      * maximum of a triangle of the node, so the smallest minimum and the smallest maximum are
-     * both <= s. */
+     * both <= s.  build() has flagged the candidates and stored their places, so the pass reads one
+     * byte per triangle and a place only for every inc-th. */
     void best_on_axis(int axis, int64_t begin, int64_t count, int inc, float& score_out, float& split_out, int& axis_out) const {
         const int32_t* imax = lists[1][axis].data() + begin;
         const float* vmax = vals[1][axis].data() + begin;
         const float* vmin = vals[0][axis].data() + begin;
         const int32_t* rk = rank_x.data();
-        const int32_t mask = inc - 1; /* inc is a power of two */
+        const uint8_t* fl = flags.data();
+        (void)inc;
         int64_t n_min = 0, n_max = 0; /* #(min <= s), #(max <= s) */
         float best = score_out, best_split = split_out;
         int32_t best_place = INT32_MAX;
         for (int64_t j = 0; j < count; j++) {
+            if (!(fl[imax[j]] & CANDIDATE)) continue;
             const int32_t place = rk[imax[j]];
-            if (place & mask) continue;
             const float s = vmax[j];
             while (n_min < count && vmin[n_min] <= s) n_min++;
             if (n_max <= j) n_max = j + 1;
@@ -271,7 +425,7 @@ struct Builder {
         for (int64_t i = 0; i < count; i++) {
             int32_t t = a[i];
             float x = v[i];
-            if (low_side[t]) { a[nl] = t; v[nl] = x; nl++; } else { high.push_back(t); high_v.push_back(x); }
+            if (flags[t] & SIDE_LOW) { a[nl] = t; v[nl] = x; nl++; } else { high.push_back(t); high_v.push_back(x); }
         }
         if (!high.empty()) {
             memcpy(a + nl, high.data(), high.size() * sizeof(int32_t));
@@ -285,19 +439,29 @@ struct Builder {
         n->depth = depth; n->begin = begin; n->count = count;
         const int32_t* ours = lists[0][0].data() + begin;
         const float inf = (float)1e100; /* FLOAT_INF narrowed, reference utils.h:10 */
+        /* The node's box (reference kdtree.cpp:51-62: running sel_min / sel_max over its triangles in
+         * by-min-x order).  The by-min and by-max segments are sorted, so the bounds are their first and
+         * last values -- as numbers.  The running form keeps the LAST of equal minima and the FIRST of
+         * equal maxima, which shows only in the sign of a zero: a zero bound is recomputed the long way. */
         for (int a = 0; a < 3; a++) {
             float lo = inf, hi = -inf;
-            const float* mn = m->bmin[a].data();
-            const float* mx = m->bmax[a].data();
-            for (int64_t i = 0; i < count; i++) { lo = sel_min(lo, mn[ours[i]]); hi = sel_max(hi, mx[ours[i]]); }
+            bool have_lo = false, have_hi = false;
+            if (plain && count > 0) {
+                lo = vals[0][a][(size_t)begin]; hi = vals[1][a][(size_t)(begin + count - 1)];
+                have_lo = lo != 0.0f; have_hi = hi != 0.0f;
+            }
+            if (!have_lo) { lo = inf; const float* mn = m->bmin[a].data(); for (int64_t i = 0; i < count; i++) lo = sel_min(lo, mn[orig[ours[i]]]); }
+            if (!have_hi) { hi = -inf; const float* mx = m->bmax[a].data(); for (int64_t i = 0; i < count; i++) hi = sel_max(hi, mx[orig[ours[i]]]); }
             n->bmin[a] = lo; n->bmax[a] = hi;
         }
         if (count <= LEAF_THRESHOLD || depth >= MAXIMUM_DEPTH) { n->leaf = true; return n; }
-        for (int64_t i = 0; i < count; i++) rank_x[ours[i]] = (int32_t)i;
         int inc = 8;                 /* reference kdtree.cpp:92-98 */
         if (count < 10000) inc = 4;
         if (count < 1000) inc = 2;
         if (count < 100) inc = 1;
+        /* split candidates: every inc-th triangle of the by-min-x list (the flags of this node's
+         * triangles hold only their parent's side bit at this point) */
+        for (int64_t i = 0; i < count; i += inc) { rank_x[ours[i]] = (int32_t)i; flags[ours[i]] |= CANDIDATE; }
         float best_score = inf, best_split = 0.0f;
         int best_axis = -1;
         bool wide = wide_threads > 1 && count >= 200000;
@@ -319,19 +483,30 @@ struct Builder {
         n->axis = best_axis; n->split = best_split;
         /* low iff the triangle's minimum on the split axis is <= the split height; every other
          * triangle goes high (reference kdtree.cpp:172-183). */
-        const float* mn = m->bmin[best_axis].data();
         int64_t lo_n = 0;
-        for (int64_t i = 0; i < count; i++) { bool b = mn[ours[i]] <= best_split; low_side[ours[i]] = b; lo_n += b; }
+        if (plain) {
+            /* in the list sorted by this very minimum the low side is a prefix (so that list is
+             * partitioned as it stands) */
+            const int32_t* seg = lists[0][best_axis].data() + begin;
+            const float* v = vals[0][best_axis].data() + begin;
+            lo_n = std::upper_bound(v, v + count, best_split) - v;
+            if (lo_n != count && lo_n != 0)
+                for (int64_t i = 0; i < count; i++) flags[seg[i]] = i < lo_n ? SIDE_LOW : 0;
+        } else {
+            const float* mn = m->bmin[best_axis].data();
+            for (int64_t i = 0; i < count; i++) { bool b = mn[orig[ours[i]]] <= best_split; flags[ours[i]] = b ? SIDE_LOW : 0; lo_n += b; }
+        }
         if (lo_n == count || lo_n == 0) { /* reference kdtree.cpp:206-208 */
             n->leaf = true; n->axis = 0; n->split = 0;
             return n;
         }
+        const int skip = plain ? best_axis : -1;   /* the by-min list of the split axis */
         if (wide) {
             std::thread th[6];
-            for (int k = 0; k < 6; k++) th[k] = std::thread([&, k]() { partition(k / 3, k % 3, begin, count); });
-            for (int k = 0; k < 6; k++) th[k].join();
+            for (int k = 0; k < 6; k++) if (k != skip) th[k] = std::thread([&, k]() { partition(k / 3, k % 3, begin, count); });
+            for (int k = 0; k < 6; k++) if (k != skip) th[k].join();
         } else {
-            for (int k = 0; k < 6; k++) partition(k / 3, k % 3, begin, count);
+            for (int k = 0; k < 6; k++) if (k != skip) partition(k / 3, k % 3, begin, count);
         }
         if (depth < spawn_depth) {
             std::thread th([&]() { n->lo = build(depth + 1, begin, lo_n); });
@@ -344,41 +519,124 @@ struct Builder {
         return n;
     }
 
+    /* Builder numbers by grid cell: remap[mesh index] = number; fills orig. */
+    void number_by_cell(std::vector<int32_t>& remap, int threads) {
+        const int64_t n = m->n;
+        float lo[3], scale[3];
+        for (int a = 0; a < 3; a++) {
+            float mn = (float)1e100, mx = -(float)1e100;
+            const float* c = m->bmin[a].data();
+            for (int64_t i = 0; i < n; i++) { mn = c[i] < mn ? c[i] : mn; mx = c[i] > mx ? c[i] : mx; }
+            lo[a] = mn;
+            const float w = mx - mn;
+            scale[a] = (w > 0.0f && w < (float)1e30) ? 64.0f / w : 0.0f;
+        }
+        std::vector<uint32_t> cell((size_t)n);
+        parallel_ranges(n, threads, [&](int64_t first, int64_t last) {
+            for (int64_t i = first; i < last; i++) {
+                uint32_t key = 0;
+                for (int a = 0; a < 3; a++) {
+                    const float f = (m->bmin[a][(size_t)i] - lo[a]) * scale[a];
+                    const uint32_t q = f >= 63.0f ? 63u : f >= 0.0f ? (uint32_t)f : 0u;   /* NaN -> 0 */
+                    for (int b = 0; b < 6; b++) key |= ((q >> b) & 1u) << (3 * b + a);
+                }
+                cell[(size_t)i] = key;
+            }
+        });
+        std::vector<int64_t> start((size_t)(1 << 18) + 1, 0);
+        for (int64_t i = 0; i < n; i++) start[(size_t)cell[(size_t)i] + 1]++;
+        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+        remap.resize((size_t)n);
+        orig.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t at = start[(size_t)cell[(size_t)i]]++;
+            remap[(size_t)i] = (int32_t)at;
+            orig[(size_t)at] = (int32_t)i;
+        }
+    }
+
     /* Six index lists sorted once with std::sort and a strict '<' on one box coordinate
      * (reference kdtree.cpp:479-494, comparator :404-409).  Ties end up in whatever order
      * libstdc++'s introsort leaves for the identity input sequence, so the same call on the
-     * same sequence is the only way to reproduce the reference's leaf order. */
+     * same sequence is the only way to reproduce the reference's leaf order.  std::sort's moves
+     * depend on nothing but the outcomes of its comparisons, so sorting {coordinate, index} pairs by
+     * the coordinate performs the same moves as sorting the indices with the reference's indirect
+     * comparator -- the same permutation, ties included -- without a random memory access per
+     * comparison. */
     BNode* run(int threads) {
         int64_t n = m->n;
+        const double t_begin = now_s();
         std::vector<std::thread> pool;
+        std::atomic<bool> any_nan(false);
+        /* each of the six sorts may use about a third of the threads */
+        const bool parallel_sort = threads > 6 && n >= (1 << 20) && keyed_sort_matches_std();
+        const int64_t spawn_min = std::max<int64_t>(1 << 16, n / (8 * std::max(1, threads / 3)));
+        if (getenv("PT_BUILD_TIMING") && threads > 6 && !keyed_sort_matches_std()) fprintf(stderr, "[build] parallel sort differs from std::sort here: not used\n");
         for (int k = 0; k < 6; k++) {
-            auto job = [this, k, n]() {
+            auto job = [this, k, n, &any_nan, parallel_sort, spawn_min]() {
                 int mm = k / 3, axis = k % 3;
-                std::vector<int32_t>& l = lists[mm][axis];
-                l.resize((size_t)n);
-                for (int64_t i = 0; i < n; i++) l[i] = (int32_t)i;
                 const float* c = coord(mm, axis);
-                std::sort(l.begin(), l.end(), [c](const int& a, const int& b) { return c[a] < c[b]; });
+                std::vector<Keyed> keyed((size_t)n);
+                bool nan = false;
+                for (int64_t i = 0; i < n; i++) { keyed[(size_t)i].key = c[i]; keyed[(size_t)i].index = (int32_t)i; nan |= c[i] != c[i]; }
+                if (nan) any_nan = true;
+                if (parallel_sort) keyed_sort(keyed.data(), keyed.data() + n, spawn_min);
+                else std::sort(keyed.begin(), keyed.end(), key_less);
+                std::vector<int32_t>& l = lists[mm][axis];
                 std::vector<float>& v = vals[mm][axis];
+                l.resize((size_t)n);
                 v.resize((size_t)n);
-                for (int64_t i = 0; i < n; i++) v[i] = c[l[i]];
+                for (int64_t i = 0; i < n; i++) { l[(size_t)i] = keyed[(size_t)i].index; v[(size_t)i] = keyed[(size_t)i].key; }
+            };
+            if (threads > 1) pool.emplace_back(job); else job();
+        }
+        std::vector<int32_t> remap;
+        number_by_cell(remap, threads > 1 ? std::max(1, threads / 4) : 1);   /* beside the sorts */
+        for (auto& t : pool) t.join();
+        plain = !any_nan;
+        pool.clear();
+        for (int k = 0; k < 6; k++) {
+            auto job = [this, k, n, &remap]() {
+                int32_t* l = lists[k / 3][k % 3].data();
+                for (int64_t i = 0; i < n; i++) l[i] = remap[(size_t)l[i]];
             };
             if (threads > 1) pool.emplace_back(job); else job();
         }
         for (auto& t : pool) t.join();
-        low_side.assign((size_t)n, 0);
+        std::vector<int32_t>().swap(remap);
+        if (getenv("PT_BUILD_TIMING")) fprintf(stderr, "[build] sorts done at %.2f s\n", now_s() - t_begin);
+        flags.assign((size_t)n, 0);
         rank_x.assign((size_t)n, 0);
         spawn_depth = 0;
         while ((1 << spawn_depth) < threads) spawn_depth++;
         wide_threads = threads;
-        return build(0, 0, n);
+        BNode* root = build(0, 0, n);
+        /* the leaf-order permutation, in the mesh's indices again */
+        std::vector<int32_t>& perm = lists[0][0];
+        parallel_ranges(n, threads, [&](int64_t first, int64_t last) { for (int64_t i = first; i < last; i++) perm[(size_t)i] = orig[(size_t)perm[(size_t)i]]; });
+        if (getenv("PT_BUILD_TIMING")) fprintf(stderr, "[build] tree done at %.2f s\n", now_s() - t_begin);
+        return root;
     }
+};
+
+/* An array whose elements start out uninitialised (a std::vector would clear gigabytes on one
+ * thread before the parallel pass overwrites every byte). */
+template <class T>
+struct RawArray {
+    T* p = nullptr;
+    ~RawArray() { free(p); }
+    void resize(size_t n) { free(p); p = (T*)malloc(std::max<size_t>(n, 1) * sizeof(T)); if (!p) throw std::bad_alloc(); }
+    T* data() { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    RawArray() = default;
+    RawArray(const RawArray&) = delete;
+    RawArray& operator=(const RawArray&) = delete;
 };
 
 struct Flat {
     std::vector<pt_flat_node> nodes;
-    std::vector<pt_tri_isect> tris;
-    std::vector<pt_tri_shade> shade;
+    RawArray<pt_tri_isect> tris;     /* every field of every record is written by flatten() */
+    RawArray<pt_tri_shade> shade;
     pt_flat_scene desc;
 };
 
@@ -404,14 +662,22 @@ uint32_t flatten_rec(const BNode* n, Flat& f, uint32_t& max_depth) {
     return me;
 }
 
-void mark_leaf_counts(const BNode* n, Flat& f) {
+/* `spawn` levels of the tree hand their low subtree to a thread of its own (subtrees own disjoint
+ * ranges of the triangle array). */
+void mark_leaf_counts(const BNode* n, Flat& f, int spawn) {
     if (n->leaf) {
         if (n->count > 0) f.tris[(size_t)n->begin].leaf_count = (uint32_t)n->count;
         for (int64_t k = 0; k < n->count; k++) f.tris[(size_t)(n->begin + k)].leaf_remaining = (uint32_t)(n->count - 1 - k);
         return;
     }
-    mark_leaf_counts(n->lo, f);
-    mark_leaf_counts(n->hi, f);
+    if (spawn > 0) {
+        std::thread low([n, &f, spawn]() { mark_leaf_counts(n->lo, f, spawn - 1); });
+        mark_leaf_counts(n->hi, f, spawn - 1);
+        low.join();
+        return;
+    }
+    mark_leaf_counts(n->lo, f, 0);
+    mark_leaf_counts(n->hi, f, 0);
 }
 
 /* Triangle::project_point_to_given_altitude's plane parameter (reference utils.cpp:167). */
@@ -447,7 +713,7 @@ void flatten(const Mesh& m, const BNode* root, const std::vector<int32_t>& perm,
         ts.d1_x = d1.x; ts.d1_y = d1.y; ts.d1_z = d1.z;
     }
     });
-    mark_leaf_counts(root, f);
+    { int spawn = 0; while ((1 << spawn) < threads && spawn < 6) spawn++; mark_leaf_counts(root, f, m.n >= (1 << 18) ? spawn : 0); }
     memset(&f.desc, 0, sizeof(f.desc));
     f.desc.n_nodes = f.nodes.size();
     f.desc.n_tris = (uint64_t)m.n;
@@ -488,7 +754,7 @@ struct pth_scene {
     ~pth_scene() { delete root; }
 };
 
-static pth_scene* finish(pth_scene* s, int threads) {
+static pth_scene* finish(pth_scene* s, int threads, pth_mesh_ready_fn mesh_ready = nullptr, void* ctx = nullptr) {
     if (threads <= 0) threads = default_threads();
     if (s->mesh.n >= (int64_t)PT_MAX_TRIANGLES) { delete s; return nullptr; }
     /* The tree needs only the triangles' boxes and the vertex normals only their positions, so
@@ -496,8 +762,12 @@ static pth_scene* finish(pth_scene* s, int threads) {
      * normals finish first and the build's own threads then have the machine). */
     double t0 = now_s(), t_normals_end = t0;
     std::thread normals;
-    if (threads > 1) normals = std::thread([s, threads, &t_normals_end]() { vertex_normals(s->mesh, std::max(1, threads / 2)); t_normals_end = now_s(); });
-    else { vertex_normals(s->mesh, 1); t_normals_end = now_s(); }
+    if (threads > 1) normals = std::thread([s, threads, &t_normals_end, mesh_ready, ctx]() {
+        vertex_normals(s->mesh, std::max(1, threads / 2));
+        t_normals_end = now_s();
+        if (mesh_ready) mesh_ready(s, ctx);
+    });
+    else { vertex_normals(s->mesh, 1); t_normals_end = now_s(); if (mesh_ready) mesh_ready(s, ctx); }
     double t1 = now_s();
     Builder b;
     b.m = &s->mesh;
@@ -514,12 +784,21 @@ static pth_scene* finish(pth_scene* s, int threads) {
 
 extern "C" {
 
-pth_scene* pth_scene_from_stl(const char* path, int threads) {
+pth_scene* pth_scene_from_stl(const char* path, int threads) { return pth_scene_from_stl_with(path, threads, nullptr, nullptr); }
+
+pth_scene* pth_scene_from_stl_with(const char* path, int threads, pth_mesh_ready_fn mesh_ready, void* ctx) {
     std::vector<float> soup;
-    if (!path || !load_stl(path, soup)) return nullptr;
+    const int use = threads > 0 ? threads : default_threads();
+    const double t0 = now_s();
+    if (!path || !load_stl(path, soup, use)) return nullptr;
+    const double t1 = now_s();
     pth_scene* s = new pth_scene();
-    mesh_from_soup(s->mesh, soup.data(), (int64_t)(soup.size() / 9), threads > 0 ? threads : default_threads());
-    return finish(s, threads);
+    mesh_from_soup(s->mesh, soup.data(), (int64_t)(soup.size() / 9), use);
+    std::vector<float>().swap(soup);
+    if (getenv("PT_BUILD_TIMING")) fprintf(stderr, "[scene] file read %.2f s, triangles %.2f s\n", t1 - t0, now_s() - t1);
+    s = finish(s, threads, mesh_ready, ctx);
+    if (s && getenv("PT_BUILD_TIMING")) fprintf(stderr, "[scene] normals %.2f s beside tree %.2f s, flat arrays %.2f s\n", s->t_normals, s->t_build, s->t_flatten);
+    return s;
 }
 
 pth_scene* pth_scene_from_triangles(const float* verts, int64_t n, int threads) {
@@ -537,18 +816,26 @@ const pt_flat_scene* pth_flat_scene(const pth_scene* s) { return &s->flat.desc; 
 
 void pth_timings(const pth_scene* s, double out[3]) { out[0] = s->t_normals; out[1] = s->t_build; out[2] = s->t_flatten; }
 
+static void triangle_data_range(const Mesh& m, int64_t first, int64_t last, float* out) {
+    for (int64_t i = first; i < last; i++) {
+        F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
+        const F3 v[9] = {m.p0[i], m.p1[i], m.p2[i], e1, e2, m.normal[i], m.vn0[i], sub(m.vn1[i], m.vn0[i]), sub(m.vn2[i], m.vn0[i])};
+        float* o = out + 30 * (i - first);
+        for (int k = 0; k < 9; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
+        o[27] = plane_of(m.normal[i], m.p0[i], m.p1[i], m.p2[i]);
+        o[28] = o[29] = 0.0f;
+    }
+}
+
 void pth_triangle_data(const pth_scene* s, float* out) {
     const Mesh& m = s->mesh;
-    parallel_ranges(m.n, default_threads(), [&m, out](int64_t first, int64_t last) {
-        for (int64_t i = first; i < last; i++) {
-            F3 e1 = sub(m.p1[i], m.p0[i]), e2 = sub(m.p2[i], m.p0[i]);
-            const F3 v[9] = {m.p0[i], m.p1[i], m.p2[i], e1, e2, m.normal[i], m.vn0[i], sub(m.vn1[i], m.vn0[i]), sub(m.vn2[i], m.vn0[i])};
-            float* o = out + 30 * i;
-            for (int k = 0; k < 9; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
-            o[27] = plane_of(m.normal[i], m.p0[i], m.p1[i], m.p2[i]);
-            o[28] = o[29] = 0.0f;
-        }
-    });
+    parallel_ranges(m.n, default_threads(), [&m, out](int64_t first, int64_t last) { triangle_data_range(m, first, last, out + 30 * first); });
+}
+
+void pth_triangle_data_range(const pth_scene* s, int64_t first, int64_t last, float* out) {
+    if (first < 0) first = 0;
+    if (last > s->mesh.n) last = s->mesh.n;
+    if (first < last) triangle_data_range(s->mesh, first, last, out);
 }
 
 void pth_tree_stats(const pth_scene* s, int64_t stats[5]) {
