@@ -46,6 +46,10 @@ void pth_triangle_data(const pth_scene* s, float* out30);
  * (last - first) * 30 floats. */
 void pth_triangle_data_range(const pth_scene* s, int64_t first, int64_t last, float* out30);
 
+/* 1 if the library's multi-threaded restatement of std::sort leaves a tie-heavy test array exactly
+ * as this C++ library's std::sort does (the builder uses it only then, std::sort otherwise), else 0. */
+int pth_parallel_sort_matches_std(void);
+
 /* stats[0]=nodes, [1]=leaves, [2]=max depth, [3]=largest leaf, [4]=sum of leaf sizes. */
 void pth_tree_stats(const pth_scene* s, int64_t stats[5]);
 /* Pre-order dump of the pointer-free build tree: 10 floats per node {is_leaf, axis, split,

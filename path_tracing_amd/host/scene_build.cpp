@@ -810,6 +810,8 @@ pth_scene* pth_scene_from_triangles(const float* verts, int64_t n, int threads) 
 
 void pth_scene_destroy(pth_scene* s) { delete s; }
 
+int pth_parallel_sort_matches_std(void) { return keyed_sort_matches_std() ? 1 : 0; }
+
 int64_t pth_num_triangles(const pth_scene* s) { return s->mesh.n; }
 
 const pt_flat_scene* pth_flat_scene(const pth_scene* s) { return &s->flat.desc; }

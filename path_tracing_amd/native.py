@@ -88,6 +88,11 @@ def host_lib():
         L.pth_timings.argtypes = [vp, vp]
         L.pth_triangle_data.argtypes = [vp, vp]
         L.pth_tree_stats.argtypes = [vp, vp]
+        L.pth_triangle_data_range.argtypes = [vp, i64, i64, vp]
+        L.pth_parallel_sort_matches_std.restype = i32
+        L.pth_parallel_sort_matches_std.argtypes = []
+        L.pth_scene_from_stl_with.restype = vp
+        L.pth_scene_from_stl_with.argtypes = [C.c_char_p, i32, vp, vp]
         L.pth_tree_dump.argtypes = [vp, vp, vp]
         _host = L
     return _host

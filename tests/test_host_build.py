@@ -133,3 +133,79 @@ def test_tree_identity_at_full_size():
         assert np.array_equal(bits(nodes), bits(want_nodes)), threads
         assert np.array_equal(leaves, want_leaves), threads
         host.close()
+
+
+def test_parallel_sort_is_std_sort():
+    """The builder's lists must come out as std::sort leaves them, ties included (kdtree.cpp:479-494).
+    Its multi-threaded restatement of that algorithm checks itself against std::sort; here the check
+    must say "identical" (with another C++ library it may not, and the builder then sorts with
+    std::sort)."""
+    from path_tracing_amd import native
+    assert native.host_lib().pth_parallel_sort_matches_std() == 1
+
+
+@pytest.mark.parametrize("kind", ["lattice", "zero_planes", "negative_zero_planes"])
+def test_tie_heavy_meshes_at_parallel_size(kind):
+    """More than 2^20 triangles (the size from which the lists are sorted by several threads and the
+    nodes' boxes are read off the sorted segments) on meshes made of ties: lattice coordinates, and
+    boxes that end on planes of +0 and -0, where the running minimum of the reference keeps the sign
+    of the LAST zero and the running maximum that of the FIRST (kdtree.cpp:51-62).  Host tree ==
+    oracle tree bit for bit."""
+    rng = np.random.default_rng(11)
+    n = (1 << 20) + 4097
+    if kind == "lattice":
+        t = rng.integers(-6, 7, size=(n, 3, 3)).astype(np.float32) * 0.125
+        t[rng.random(t.shape) < 0.03] = -0.0
+    elif kind == "zero_planes":
+        t = rng.random((n, 3, 3)).astype(np.float32)
+        t[:, 0, :] = 0.0
+        t[::2, 0, :] = -0.0
+    else:
+        t = -rng.random((n, 3, 3)).astype(np.float32)
+        t[:, 1, :] = -0.0
+        t[::3, 1, :] = 0.0
+    t = np.ascontiguousarray(t.reshape(-1, 9))
+    oracle = orc.Scene(t, threads=8)
+    want_nodes, want_leaves = oracle.tree_dump()
+    del oracle
+    for threads in (8, 1):
+        host = pta.HostScene(t, threads=threads)
+        nodes, leaves = host.tree_dump()
+        assert np.array_equal(bits(nodes), bits(want_nodes)), threads
+        assert np.array_equal(leaves, want_leaves), threads
+        host.close()
+
+
+def test_triangle_data_ranges_and_mesh_ready_callback(scene_small):
+    import ctypes as C
+    from path_tracing_amd import native
+    L = native.host_lib()
+    h = scene_small.host
+    whole = h.triangle_data()
+    part = np.zeros((50, 30), np.float32)
+    L.pth_triangle_data_range(h.h, 7, 57, part.ctypes.data)
+    assert np.array_equal(bits(part), bits(whole[7:57]))
+    # out-of-range ends are clipped
+    tail = np.full((10, 30), 7.0, np.float32)
+    L.pth_triangle_data_range(h.h, h.n - 3, h.n + 100, tail.ctypes.data)
+    assert np.array_equal(bits(tail[:3]), bits(whole[-3:])) and (tail[3:] == 7.0).all()
+    # the callback sees the final per-triangle data, once, before the constructor returns
+    seen = []
+    def ready(scene, ctx):
+        n = L.pth_num_triangles(scene)
+        got = np.zeros((n, 30), np.float32)
+        L.pth_triangle_data_range(scene, 0, n, got.ctypes.data)
+        seen.append(got)
+    cb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)(ready)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "m.stl")
+        pta.meshgen.write_stl(path, scene_small.tris)
+        for threads in (1, 4):
+            seen.clear()
+            hs = L.pth_scene_from_stl_with(path.encode(), threads, C.cast(cb, C.c_void_p), None)
+            assert hs and len(seen) == 1
+            assert np.array_equal(bits(seen[0]), bits(whole))
+            L.pth_scene_destroy(hs)
+        seen.clear()
+        assert not L.pth_scene_from_stl_with(os.path.join(tmp, "missing.stl").encode(), 2, C.cast(cb, C.c_void_p), None)
+        assert seen == []
