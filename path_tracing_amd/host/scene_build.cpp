@@ -297,6 +297,10 @@ inline void insertion_pass(Keyed* first, Keyed* last) {
     }
 }
 
+/* Threads that sorts have started and not yet joined, process-wide, and the most there may be. */
+std::atomic<int> g_sort_threads(0);
+const int MAX_SORT_THREADS = 96;
+
 void keyed_sort_range(Keyed* first, Keyed* last, int depth, int64_t spawn_min) {
     std::vector<std::thread> kids;
     std::vector<std::pair<Keyed*, Keyed*>> mine;   /* ranges this thread finishes itself */
@@ -304,13 +308,17 @@ void keyed_sort_range(Keyed* first, Keyed* last, int depth, int64_t spawn_min) {
         if (depth == 0) { std::partial_sort(first, last, last, key_less); break; }
         --depth;
         Keyed* cut = partition_step(first, last);
-        if (last - cut >= spawn_min) kids.emplace_back(keyed_sort_range, cut, last, depth, spawn_min);
-        else { quick_steps(cut, last, depth); mine.emplace_back(cut, last); }
+        bool handed_over = false;
+        if (last - cut >= spawn_min) {
+            if (g_sort_threads.fetch_add(1) < MAX_SORT_THREADS) { kids.emplace_back(keyed_sort_range, cut, last, depth, spawn_min); handed_over = true; }
+            else g_sort_threads.fetch_sub(1);
+        }
+        if (!handed_over) { quick_steps(cut, last, depth); mine.emplace_back(cut, last); }
         last = cut;
     }
     mine.emplace_back(first, last);
     for (auto& r : mine) insertion_pass(r.first, r.second);
-    for (auto& t : kids) t.join();
+    for (auto& t : kids) { t.join(); g_sort_threads.fetch_sub(1); }
 }
 
 int floor_log2(int64_t n) { int k = 0; while (n > 1) { n >>= 1; k++; } return k; }
