@@ -219,7 +219,10 @@ def main():
     def frame(total, base, tally):
         """One frame of `total` samples per pixel, split over the ranks by sample index."""
         first, count = partition_samples(total, world, rank)
-        render_range(base + first, count, tally)
+        # one call with all of the rank's samples: the library cuts it into screen bands that each
+        # carry every sample (more samples of a patch in flight = fewer distinct leaves touched)
+        if count:
+            tally.add(film.render(cam, lights, [(0, 0, -1, -1, base + first, count)], seed=args.seed, want_stats=True))
 
     total_steps = args.warmup + args.steps
 

@@ -2421,7 +2421,35 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         if (max_padded > per_batch || total_paths <= floor_paths) { n_lanes = 1; per_batch = limit; }
     }
     per_batch = std::min(per_batch, (size_t)(PT_MAX_RAYS_PER_CALL / (size_t)std::max(n_lights, 1)));
-    if (max_padded > per_batch) return fail(PT_ERR_LIMIT, "one pass of this rectangle exceeds PT_BATCH_PATHS");
+    /* A pass whose samples do not fit one batch is cut into horizontal bands that do, each with ALL of
+     * its samples, rather than into sample ranges of the whole rectangle: the more samples of a screen
+     * patch are in flight together, the fewer distinct leaves the rays in flight touch (measured on the
+     * 21.5 M-triangle scene at 3840x2160: 16 / 32 / 64 samples per batch = 2 047 / 2 190 / 2 262
+     * Mrays/s).  A pixel's samples still reach the film in sample order, so the picture is the same.
+     * Bands that are still too large (fewer than 8 rows fit) are cut by samples below. */
+    {
+        std::vector<Clamped> cut;
+        for (const Clamped& c : work) {
+            const size_t row_paths = (size_t)c.bx * 64;   /* one row of 8x8 blocks, one sample */
+            const size_t block_rows = (size_t)(c.p.h + 7) / 8;
+            size_t fit = per_batch / (row_paths * c.p.n_samples);   /* block rows whose samples fit one batch */
+            if (c.padded * c.p.n_samples <= per_batch || block_rows <= 1) { cut.push_back(c); continue; }
+            if (fit < 1) fit = 1;
+            /* equal bands rather than full ones and a remainder */
+            const size_t n_bands = (block_rows + fit - 1) / fit;
+            const size_t rows_each = (block_rows + n_bands - 1) / n_bands;
+            for (size_t r0 = 0; r0 < block_rows; r0 += rows_each) {
+                Clamped b = c;
+                b.p.y = c.p.y + (int32_t)(r0 * 8);
+                b.p.h = (int32_t)std::min<size_t>(rows_each * 8, (size_t)c.p.h - r0 * 8);
+                b.padded = (size_t)c.bx * ((size_t)(b.p.h + 7) / 8) * 64;
+                cut.push_back(b);
+            }
+        }
+        work.swap(cut);
+        for (const Clamped& c : work)
+            if (c.padded > per_batch) return fail(PT_ERR_LIMIT, "one row of 8x8-pixel blocks of this rectangle exceeds PT_BATCH_PATHS");
+    }
     LaunchCtx ctx[RENDER_LANES] = {{s->stream, s->d_spill}, {nullptr, nullptr}};
     if (n_lanes == 2) {
         rc = ensure_second_lane(s);
@@ -2472,6 +2500,9 @@ int pt_render_passes(pt_film* f, const pt_camera* cam, const pt_light* lights, i
         int r2 = harvest(li);
         if (r2) return r2;
         size_t cap = ((batch_paths + ((size_t)1 << 20) - 1) >> 20) << 20;
+        /* a call that fills more than half of the allowance takes all of it at once: growing the
+         * scratch later means freeing and allocating it anew, which costs seconds at this size */
+        if (total_paths > per_batch / 2 && cap > ln.cap_paths) cap = std::max(cap, per_batch);
         r2 = lane_ensure_scratch(&ln, cap, (uint32_t)n_lights, batch.size());
         if (r2) return r2;
         if (n_lights > 0) HIP_TRY(hipMemcpyAsync(ln.d_lights, hl, sizeof(DLight) * n_lights, hipMemcpyHostToDevice, ctx[li].stream));

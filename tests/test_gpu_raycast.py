@@ -176,6 +176,35 @@ def test_two_render_lanes_match_one(scene_small, monkeypatch):
     assert (p3 == 2 * S).all()
 
 
+def test_oversized_passes_are_cut_into_bands(scene_small, monkeypatch):
+    """A pass whose samples exceed the batch allowance is rendered as horizontal bands that each carry
+    all of its samples (bands too large even at eight rows are cut by samples as well).  Whatever the
+    cut, the film and the ray counts are those of the uncut pass, bit for bit: a pixel's samples reach
+    the film in sample order.  Odd sizes and an offset rectangle included."""
+    sc = scene_small
+    W, H, S = 500, 301, 24
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
+    film = pta.Film(sc.gpu, W, H)
+    passes = [(0, 0, -1, -1, 0, S), (37, 50, 333, 173, S, 7)]
+    monkeypatch.setenv("PT_RENDER_LANES", "1")
+    monkeypatch.setenv("PT_BATCH_PATHS", str(1 << 26))          # everything in one batch
+    want_st = film.render(cam, pta.cli_lights(), passes, seed=5)
+    want, want_p = film.read()
+    assert want_st.camera_samples == W * H * S + 333 * 173 * 7
+    per_row = ((W + 7) // 8) * 64                                # one row of 8x8 blocks, one sample
+    for allowance in (per_row * S * 5 + 17,                       # bands of five block rows
+                      per_row * S + 1,                            # bands of one block row
+                      per_row * 5):                               # one block row holds only five samples
+        film.zero()
+        monkeypatch.setenv("PT_BATCH_PATHS", str(max(allowance, 4096)))
+        st = film.render(cam, pta.cli_lights(), passes, seed=5)
+        got, got_p = film.read()
+        assert np.array_equal(got_p, want_p), allowance
+        assert (st.camera_samples, st.closest_rays, st.shadow_rays, st.shadow_rays_traced) == \
+               (want_st.camera_samples, want_st.closest_rays, want_st.shadow_rays, want_st.shadow_rays_traced), allowance
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), allowance
+
+
 def test_bounded_occlusion(scene_small, scene_medium):
     """pt_raycast_occluded (a flagged extension, no counterpart in the reference): visible iff
     no triangle in any node whose box the ray hits is hit at t < max_t -- the oracle's
