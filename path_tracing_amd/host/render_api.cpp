@@ -216,9 +216,25 @@ Scene::Scene(string path) : main_camera(Vec(-1, 0, 0), Vec(1, 0, 0)) { /* integr
         for (int i = 0; i < n; i++) (void)pt_device_prepare(i);
         return nullptr;
     }, nullptr) == 0;
-    /* the host-side mesh is filled in beside the tree build, as soon as the vertex normals exist */
+    /* The host-side mesh is filled in beside the tree build, as soon as the vertex normals exist.  Its
+     * memory (156 bytes per triangle, cleared by the vector on one thread) is made ready even earlier,
+     * from the triangle count in the file's header, while the file is still being read. */
     mesh = new vector<Triangle>();
-    pth_scene* built = pth_scene_from_stl_with(path.c_str(), 0, [](const pth_scene* ready, void* into) { fill_triangles(ready, *(vector<Triangle>*)into); }, mesh);
+    struct Early { vector<Triangle>* mesh; thread sizing; } early{mesh, thread()};
+    {
+        uint32_t count = 0;
+        FILE* fp = fopen(path.c_str(), "rb");
+        const bool have = fp && fseek(fp, 80, SEEK_SET) == 0 && fread(&count, 4, 1, fp) == 1 && fseek(fp, 0, SEEK_END) == 0 &&
+                          ftell(fp) >= 84 + (long)count * 50;
+        if (fp) fclose(fp);
+        if (have && count >= (1u << 18)) early.sizing = thread([count, m = mesh]() { m->resize(count); });
+    }
+    pth_scene* built = pth_scene_from_stl_with(path.c_str(), 0, [](const pth_scene* ready, void* ctx) {
+        Early* e = (Early*)ctx;
+        if (e->sizing.joinable()) e->sizing.join();
+        fill_triangles(ready, *e->mesh);
+    }, &early);
+    if (early.sizing.joinable()) early.sizing.join();   /* the file turned out to be unreadable */
     if (warming) pthread_join(warm, nullptr);
     if (built == nullptr) {
         cout << "Couldn't read input file." << endl;

@@ -100,14 +100,14 @@ def test_cpp_api_against_oracle(tmp_path, scene_small):
 
 
 def test_failed_render_is_reported(tmp_path, scene_small):
-    """A render call that fails on the GPU (here: a tile larger than the batch allowance) must not
-    end in a picture and exit code 0."""
+    """A render call that fails on the GPU (here: a tile of which even one row of 8x8-pixel blocks is
+    larger than the batch allowance) must not end in a picture and exit code 0."""
     cli = os.path.join(ROOT, "path_tracing_amd", "bin", "cli_render")
     stl = str(tmp_path / "standin.stl")
     out = str(tmp_path / "never.png")
     pta.meshgen.write_stl(stl, scene_small.tris)
-    res = subprocess.run([cli, stl, "--output", out, "--width", "256", "--height", "256", "--samples", "2", "--tile-width", "128",
-                          "--tile-height", "128"], capture_output=True, text=True, timeout=300,
+    res = subprocess.run([cli, stl, "--output", out, "--width", "1024", "--height", "64", "--samples", "2", "--tile-width", "1024",
+                          "--tile-height", "64"], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, PT_BATCH_PATHS="4096"))
     assert res.returncode == 1, res.stdout + res.stderr
     assert "Render failed: " in res.stdout and "PT_BATCH_PATHS" in res.stdout
