@@ -70,6 +70,11 @@ struct DScene {
     uint32_t q_root;      /* the root's position for walks on q-nodes; PT_REF_NONE: the scene has none */
     uint32_t q_root_exact; /* ... for rays that must stay on exact records (not tame) */
     QGrid grid;
+    /* wave-wide leaf tests (k_shadow_leafwise): a copy of the node records whose leaf references name
+     * the leaf's place in `soa`, the triangles stored component by component */
+    const char* leafwise_nodes;
+    const float* soa;
+    uint32_t leafwise_root;
 };
 
 struct RaySoA {
@@ -879,6 +884,293 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(NW 
     }
 }
 
+/*
+ * Any-hit walk with WAVE-WIDE leaf tests, for scenes whose leaves are large (the reference caps its
+ * tree at 19 levels, kdtree.cpp:13, so tens of millions of triangles end up 40 to a leaf).
+ *
+ * In k_trace a lane walks its leaf alone, a few 48-byte records per round, each through per-lane
+ * addresses: on such scenes the kernels are bound by the rate at which the vector-memory path takes
+ * distinct lane addresses (asking a round early for the next round's lines, two more addresses per
+ * lane, made them 20 % slower).  Here a lane that reaches a leaf does not test it: in the next round
+ * the WAVE tests that leaf for it, one triangle per lane, from a copy of the triangles stored
+ * component by component in pieces of 64 (nine rows of 64 floats per piece, a leaf of more than 64
+ * triangles in consecutive pieces), so that a piece is fetched by nine loads of consecutive words at
+ * one scalar base -- a few dozen cache-line lookups instead of three per triangle -- and 36 instead
+ * of 48 bytes per triangle.  The pending leaves of a round are worked off one piece after the other,
+ * the loads of the next two pieces in flight; the ray is read from its owner's registers.
+ *
+ * The answer of an any-hit walk does not depend on the order of the tests (traverse_core.h,
+ * "q-nodes"): the same leaves are entered through the same box tests, every triangle of an entered
+ * leaf meets the same triangle test, so "hit or not" is k_trace's.  Leaf references on the device are
+ * PT_REF_LEAF | first piece << 8 | count (count <= 255) in a copy of the node array made for this kernel.
+ */
+#ifndef LEAFWISE_WAVES_PER_EU
+#define LEAFWISE_WAVES_PER_EU 6
+#endif
+#define LEAFWISE_PIECE 64u                         /* triangles per piece = lanes */
+#define LEAFWISE_PIECE_WORDS (9u * LEAFWISE_PIECE)
+#define LEAFWISE_MAX_COUNT 255u
+#define LEAFWISE_MAX_PIECES (1u << 22)
+
+struct LeafPiece {            /* wave-uniform: one piece (up to 64 triangles) of one pending leaf */
+    uint64_t rest;            /* lanes whose leaves come after this one */
+    uint32_t lane;            /* the owner */
+    uint32_t piece;           /* its number in the pool */
+    uint32_t left;            /* triangles of the leaf from this piece on */
+    uint32_t valid;
+    uint32_t dead;            /* the owner has its hit: the leaf's remaining pieces are not tested */
+};
+
+/* The piece after `p` in the round's sequence: the next 64 triangles of the same leaf, else the
+ * leaf of the next lane in `rest`. */
+__device__ __forceinline__ void leaf_piece_next(LeafPiece& p, uint32_t cur) {
+    if (p.valid && p.left > LEAFWISE_PIECE) { p.left -= LEAFWISE_PIECE; p.piece += 1u; return; }
+    if (p.rest == 0ull) { p.valid = 0u; return; }
+    const uint32_t b = (uint32_t)__builtin_ctzll(p.rest);
+    p.rest &= p.rest - 1ull;
+    const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)b);
+    p.lane = b;
+    p.left = ref & 255u;
+    p.piece = (ref >> 8) & (LEAFWISE_MAX_PIECES - 1u);
+    p.valid = 1u;
+    p.dead = 0u;
+}
+
+struct Tri9 { float p0x, p0y, p0z, e1x, e1y, e1z, e2x, e2y, e2z; };
+
+/* Lane j of the wave asks for triangle j of the piece (lanes past the leaf's end repeat its last
+ * triangle): one scalar base, one 32-bit lane offset, nine constant row offsets. */
+__device__ __forceinline__ void leaf_piece_load(const LeafPiece& p, const float* __restrict__ soa, uint32_t lane, Tri9& t) {
+    if (!p.valid) return;
+    const uint32_t j = lane < p.left ? lane : p.left - 1u;
+    const char* rows = (const char*)soa + (size_t)p.piece * (LEAFWISE_PIECE_WORDS * 4u) + j * 4u;
+    t.p0x = *(const float*)(rows);
+    t.p0y = *(const float*)(rows + 1u * LEAFWISE_PIECE * 4u);
+    t.p0z = *(const float*)(rows + 2u * LEAFWISE_PIECE * 4u);
+    t.e1x = *(const float*)(rows + 3u * LEAFWISE_PIECE * 4u);
+    t.e1y = *(const float*)(rows + 4u * LEAFWISE_PIECE * 4u);
+    t.e1z = *(const float*)(rows + 5u * LEAFWISE_PIECE * 4u);
+    t.e2x = *(const float*)(rows + 6u * LEAFWISE_PIECE * 4u);
+    t.e2y = *(const float*)(rows + 7u * LEAFWISE_PIECE * 4u);
+    t.e2z = *(const float*)(rows + 8u * LEAFWISE_PIECE * 4u);
+}
+
+/* One piece against its owner's ray; the owner takes the outcome. */
+template <int MODE>
+__device__ __forceinline__ void leaf_piece_test(LeafPiece& now, const Tri9& t, Lane& L, uint32_t lane) {
+    /* the whole set is waited for here, along every path (the test below reads some of its words only
+     * behind its early exits): afterwards the set can be loaded anew without waiting for the other one */
+    asm volatile("" :: "v"(t.p0x), "v"(t.p0y), "v"(t.p0z), "v"(t.e1x), "v"(t.e1y), "v"(t.e1z), "v"(t.e2x), "v"(t.e2y), "v"(t.e2z));
+    if (now.dead) return;
+    const int b = (int)now.lane;
+    Ray9 r;
+    r.ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.ox), b));
+    r.oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.oy), b));
+    r.oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.oz), b));
+    r.dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dx), b));
+    r.dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dy), b));
+    r.dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dz), b));
+    r.rx = 0.0f; r.ry = 0.0f; r.rz = 0.0f;   /* the triangle test does not use the reciprocals */
+    /* a hit counts if it is nearer than the best so far (kdtree.cpp:286): +inf, or the light's distance */
+    const float bound = MODE == TRACE_SHADOW_BOUNDED ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.best.t), b)) : pt_inf();
+    TriData tr;
+    tr.p0x = t.p0x; tr.p0y = t.p0y; tr.p0z = t.p0z;
+    tr.e1x = t.e1x; tr.e1y = t.e1y; tr.e1z = t.e1z;
+    tr.e2x = t.e2x; tr.e2y = t.e2y; tr.e2z = t.e2z;
+    tr.mesh_index = 0u; tr.leaf_remaining = 0u;
+    float tt, uu, vv;
+    const bool hit = lane < now.left && tri_hit(tr, r, tt, uu, vv) && tt < bound;
+    const bool any = __ballot(hit) != 0ull;
+    const bool last = now.left <= LEAFWISE_PIECE;
+    /* written as selects: the owner's state stays in registers */
+    const bool mine = lane == now.lane;
+    L.found = L.found || (mine && any);
+    L.cur = (mine && (any || last)) ? PT_REF_NONE : L.cur;
+    L.sp = (mine && any) ? 0 : L.sp;
+    if (any) now.dead = 1u;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(LEAFWISE_WAVES_PER_EU))) void k_shadow_leafwise(DScene sc, TraceArgs a) {
+    static_assert(MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED, "any-hit walks only");
+    __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
+    const uint32_t n = *a.d_count * a.count_mul;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    LaneStack st;
+    st.lds = stk + STACK_PAD * TRACE_BLOCK + threadIdx.x;
+    st.stride = gridDim.x * TRACE_BLOCK;
+    st.spill = a.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
+
+    Lane L;
+    L.cur = PT_REF_NONE; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
+    L.best.t = 0.0f; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0u; L.best.mesh = 0u; L.local = 0.0f;
+    L.r.ox = L.r.oy = L.r.oz = 0.0f; L.r.dx = L.r.dy = L.r.dz = 0.0f; L.r.rx = L.r.ry = L.r.rz = 0.0f;
+    int32_t ray = -1;
+    uint32_t tgt = 0;
+    float dist = 0.0f;
+    uint32_t pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+    const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / 64);
+    uint32_t chunk = TRACE_CHUNK;
+    while (chunk < TRACE_MAX_CHUNK_MUL * TRACE_CHUNK && (uint64_t)chunk * 2u * TRACE_MIN_CHUNKS_PER_WAVE * n_waves <= n) chunk *= 2u;
+    const uint32_t total_chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
+    bool first_chunk = true;
+    /* the queue is dealt to the XCDs as in k_trace */
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t xcd_waves = n_waves >> 3;
+    const uint32_t xcd_wave = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * (TRACE_BLOCK / 64) + (threadIdx.x >> 6));
+    uint32_t from_xcd = xcd, tried = 0;
+    const bool static_only = total_chunks <= (xcd_waves / TRACE_XCD_SUPER) * TRACE_XCD_SUPER * 8u;
+    const bool scene_tame = root_is_tame(sc.root);
+
+    float4 q0, q1, q2, q3;                    /* the lane's node record for this round */
+    q0 = q1 = q2 = q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool rec_node = false;
+    bool starting = false;
+    uint32_t new_ray = 0;
+    /* leaf pieces: the lanes that held a leaf when the previous round ended, the piece the next load
+     * is for, and the two register sets the pieces alternate between */
+    uint64_t pending = 0ull;
+    LeafPiece ahead;
+    ahead.rest = 0ull; ahead.lane = 0u; ahead.piece = 0u; ahead.left = 1u; ahead.valid = 0u; ahead.dead = 0u;
+    Tri9 ta, tb;
+    ta.p0x = ta.p0y = ta.p0z = ta.e1x = ta.e1y = ta.e1z = ta.e2x = ta.e2y = ta.e2z = 0.0f;
+    tb = ta;
+    uint32_t rounds = 0;
+
+    while (true) {
+        asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                           "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist), "v"(tgt));
+        asm volatile("" :: "v"(ta.p0x), "v"(ta.p0y), "v"(ta.p0z), "v"(ta.e1x), "v"(ta.e1y), "v"(ta.e1z), "v"(ta.e2x), "v"(ta.e2y), "v"(ta.e2z));
+        asm volatile("" :: "v"(tb.p0x), "v"(tb.p0y), "v"(tb.p0z), "v"(tb.e1x), "v"(tb.e1y), "v"(tb.e1z), "v"(tb.e2x), "v"(tb.e2y), "v"(tb.e2z));
+        if (++rounds > (1u << 24)) break;   /* never reached: a wave's rounds are bounded by its rays' steps */
+
+        /* ---- the leaves that were pending when the previous round ended, piece by piece ----
+         * (a lane that is being refilled holds no leaf, and its old ray's registers are not read) */
+        if (pending) {
+            LeafPiece now;
+            now.rest = pending; now.lane = 0u; now.piece = 0u; now.left = 1u; now.valid = 0u; now.dead = 0u;
+            leaf_piece_next(now, L.cur);
+            /* pieces alternate between the two register sets, the first of a round in `ta`; when a
+             * set has been tested, the piece after the one in the other set is loaded into it */
+            while (true) {
+                leaf_piece_test<MODE>(now, ta, L, lane);
+                leaf_piece_next(ahead, L.cur);
+                leaf_piece_load(ahead, sc.soa, lane, ta);
+                leaf_piece_next(now, L.cur);
+                if (!now.valid) break;
+                leaf_piece_test<MODE>(now, tb, L, lane);
+                leaf_piece_next(ahead, L.cur);
+                leaf_piece_load(ahead, sc.soa, lane, tb);
+                leaf_piece_next(now, L.cur);
+                if (!now.valid) break;
+            }
+        }
+
+        /* ---- start the refilled lanes ---- */
+        bool defer = false;
+        if (starting) {
+            if (MODE == TRACE_SHADOW_ANY && !(dist >= 1.0f)) defer = true;
+            else {
+                ray_set_recip(L.r);
+                lane_start(L, sc.leafwise_root, sc.root, scene_tame);
+                if (MODE == TRACE_SHADOW_BOUNDED) L.best.t = dist;
+                ray = (int32_t)new_ray;
+            }
+        }
+        if (MODE == TRACE_SHADOW_ANY) {
+            const uint64_t dm = __ballot(defer);
+            if (dm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.defer_count, (uint32_t)__popcll(dm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (defer) a.defer_list[base + (uint32_t)__popcll(dm & lt_mask)] = new_ray;
+            }
+        }
+        const bool active = ray >= 0;
+
+        /* ---- one interior node per lane that has its record ---- */
+        {
+            NodeData nd;
+            nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
+            nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
+            nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
+            if (__any(rec_node && !L.tame)) {
+                if (rec_node) lane_node<true, false>(L, nd, st);
+            } else {
+                if (rec_node) lane_node<true, true>(L, nd, st);
+            }
+        }
+        if (active && L.cur == PT_REF_NONE && L.sp > 0) lane_pop<true>(L, st);
+
+        /* ---- next round's node records, and the first two pieces of the leaves now pending ---- */
+        rec_node = active && lane_has_node(L);
+        if (rec_node) {
+            const float4* rec = (const float4*)(sc.leafwise_nodes + L.cur * (uint32_t)sizeof(pt_flat_node));
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+        }
+        pending = __ballot(active && lane_has_leaf(L));
+        ahead.rest = pending; ahead.valid = 0u;
+        leaf_piece_next(ahead, L.cur);
+        leaf_piece_load(ahead, sc.soa, lane, ta);
+        leaf_piece_next(ahead, L.cur);
+        leaf_piece_load(ahead, sc.soa, lane, tb);
+
+        /* ---- retire finished rays ---- */
+        if (active && lane_finished(L)) {
+            a.vis[a.target ? tgt : (uint32_t)ray] = L.found ? 0 : 1;
+            ray = -1;
+        }
+
+        /* ---- refill idle lanes (as k_trace) ---- */
+        const uint64_t idle = __ballot(ray < 0);
+        starting = false;
+        if (idle) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (!exhausted && (n_idle >= REFILL_MIN_ANY || idle == ~0ull)) {
+                if (pool_next >= pool_end) {
+                    uint32_t c = total_chunks;
+                    if (first_chunk) {
+                        c = ((xcd_wave / TRACE_XCD_SUPER) * 8u + xcd) * TRACE_XCD_SUPER + xcd_wave % TRACE_XCD_SUPER;
+                    } else if (!static_only) {
+                        while (tried < 8u) {
+                            uint32_t k = 0;
+                            if (lane == 0) k = atomicAdd(a.d_next_chunk + from_xcd * 8u, 1u);
+                            k = xcd_waves + __builtin_amdgcn_readfirstlane(k);
+                            c = ((k / TRACE_XCD_SUPER) * 8u + from_xcd) * TRACE_XCD_SUPER + k % TRACE_XCD_SUPER;
+                            if (c < total_chunks) break;
+                            from_xcd = (from_xcd + 1u) & 7u; tried++;
+                            c = total_chunks;
+                        }
+                    }
+                    first_chunk = false;
+                    if (c < total_chunks) {
+                        const uint64_t first = (uint64_t)c * chunk;
+                        pool_next = (uint32_t)first;
+                        pool_end = (uint32_t)min((uint64_t)n, first + chunk);
+                    } else {
+                        exhausted = true;
+                    }
+                }
+                if (!exhausted) {
+                    uint32_t k = pool_next + (uint32_t)__popcll(idle & lt_mask);
+                    starting = (ray < 0) && (k < pool_end);
+                    new_ray = k;
+                    pool_next = min(pool_end, pool_next + n_idle);
+                }
+            }
+            if (exhausted && idle == ~0ull) break;
+        }
+        if (starting) {
+            dist = a.dist[new_ray]; if (a.target) tgt = a.target[new_ray];
+            L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
+            L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
+        }
+    }
+}
+
 /* ------------------------------------------------------- wavefront renderer */
 
 struct DLight { V3f pos, color; };
@@ -1335,6 +1627,53 @@ __global__ __launch_bounds__(NOALLOC_HEAD_WORDS) void k_noalloc_prepare(uint32_t
     head[threadIdx.x] = threadIdx.x == 0 ? n : 0u;
 }
 
+/* ------------------------------------------------- leaves stored by component */
+
+/* One thread per leaf: its triangles' nine floats from the 48-byte records into the nine rows of its
+ * pieces (slots past the leaf's end repeat its last triangle). */
+__global__ __launch_bounds__(256) void k_leafwise_fill(const uint32_t* __restrict__ tris, const uint32_t* __restrict__ start,
+                                                        const uint32_t* __restrict__ piece, const uint32_t* __restrict__ count,
+                                                        uint32_t n_leaves, uint32_t* __restrict__ soa) {
+    const uint32_t l = blockIdx.x * 256u + threadIdx.x;
+    if (l >= n_leaves) return;
+    const uint32_t s = start[l], cnt = count[l];
+    const uint32_t slots = ((cnt + LEAFWISE_PIECE - 1u) / LEAFWISE_PIECE) * LEAFWISE_PIECE;
+    uint32_t* dst = soa + (size_t)piece[l] * LEAFWISE_PIECE_WORDS;
+    for (uint32_t j = 0; j < slots; j++) {
+        const uint32_t* src = tris + (size_t)(s + (j < cnt ? j : cnt - 1u)) * (sizeof(pt_tri_isect) / 4);
+        uint32_t* at = dst + (size_t)(j / LEAFWISE_PIECE) * LEAFWISE_PIECE_WORDS + (j % LEAFWISE_PIECE);
+#pragma unroll
+        for (uint32_t c = 0; c < 9u; c++) at[c * LEAFWISE_PIECE] = src[c];
+    }
+}
+
+/* Host part: the node records with their leaf references rewritten, and where each leaf goes. */
+struct LeafwiseBuild {
+    std::vector<pt_flat_node> nodes;
+    std::vector<uint32_t> start, piece, count;
+    uint32_t root = PT_REF_NONE;
+    uint64_t pieces = 0;
+    bool ok = true;
+};
+
+static void leafwise_build(const pt_flat_scene* f, LeafwiseBuild& out) {
+    out.nodes.assign(f->nodes, f->nodes + f->n_nodes);
+    auto convert = [&](uint32_t ref) -> uint32_t {
+        if (!(ref & PT_REF_LEAF)) return ref;
+        const uint32_t start = ref & PT_REF_START_MASK;
+        uint32_t count = (ref >> PT_REF_COUNT_SHIFT) & PT_REF_COUNT_MASK;
+        if (count == 0) count = f->tris[start].leaf_count;
+        if (count > LEAFWISE_MAX_COUNT) { out.ok = false; return ref; }
+        const uint64_t g = out.pieces;
+        out.pieces += (count + LEAFWISE_PIECE - 1) / LEAFWISE_PIECE;
+        if (out.pieces > LEAFWISE_MAX_PIECES) { out.ok = false; return ref; }
+        out.start.push_back(start); out.piece.push_back((uint32_t)g); out.count.push_back(count);
+        return PT_REF_LEAF | ((uint32_t)g << 8) | count;
+    };
+    out.root = convert(f->root_ref);
+    for (pt_flat_node& n : out.nodes) { n.lo_ref = convert(n.lo_ref); n.hi_ref = convert(n.hi_ref); }
+}
+
 /* --------------------------------------------------------------- host side */
 
 struct TimedLaunch { int cls; hipEvent_t a, b; };
@@ -1355,6 +1694,9 @@ struct pt_scene {
     DScene d{};
     void* d_geom = nullptr;  /* nodes and triangle records */
     void* d_shade = nullptr;
+    void* d_leafwise = nullptr;   /* k_shadow_leafwise: rewritten node records, then the triangles by component */
+    bool use_leafwise = false;
+    int grid_leafwise = 0;
     uint64_t n_tris = 0;
     uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, two sets of queue heads at SMALL_HEADS0/1 */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
@@ -1557,6 +1899,41 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
      * 16 % slower than k_trace<SHADOW_ANY>). */
     s->use_dense = false;
     if (const char* e = getenv("PT_DENSE_SHADOW")) s->use_dense = atoi(e) == 1 && !with_q && largest_leaf > 0 && largest_leaf <= PT_REF_COUNT_MASK;
+    /* Wave-wide leaf tests for the light-visibility walk (k_shadow_leafwise), PT_LEAFWISE=1: every leaf
+     * at most 255 triangles. */
+    s->use_leafwise = false;
+    if (const char* e = getenv("PT_LEAFWISE")) {
+        if (atoi(e) == 1 && flat->n_tris > 0) {
+            LeafwiseBuild lw;
+            leafwise_build(flat, lw);
+            if (lw.ok) {
+                const size_t nodes_b = (std::max<size_t>(flat->n_nodes, 1) * sizeof(pt_flat_node) + 255) & ~(size_t)255;
+                const size_t soa_b = std::max<uint64_t>(lw.pieces, 1) * LEAFWISE_PIECE_WORDS * sizeof(float);
+                const size_t nl = lw.start.size();
+                uint32_t* d_tab = nullptr;
+                bool good = hipMalloc(&s->d_leafwise, nodes_b + soa_b) == hipSuccess && hipMalloc((void**)&d_tab, std::max<size_t>(nl, 1) * 12) == hipSuccess;
+                good = good && hipMemset((char*)s->d_leafwise + nodes_b, 0, soa_b) == hipSuccess;
+                if (good && flat->n_nodes) good = hipMemcpy(s->d_leafwise, lw.nodes.data(), flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
+                if (good && nl) {
+                    good = hipMemcpy(d_tab, lw.start.data(), nl * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                           hipMemcpy(d_tab + nl, lw.piece.data(), nl * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                           hipMemcpy(d_tab + 2 * nl, lw.count.data(), nl * 4, hipMemcpyHostToDevice) == hipSuccess;
+                    if (good) {
+                        hipLaunchKernelGGL(k_leafwise_fill, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s->stream,
+                                           (const uint32_t*)((const char*)s->d_geom + tris_off), d_tab, d_tab + nl, d_tab + 2 * nl, (uint32_t)nl,
+                                           (uint32_t*)((char*)s->d_leafwise + nodes_b));
+                        good = hipGetLastError() == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess;
+                    }
+                }
+                if (d_tab) (void)hipFree(d_tab);
+                if (!good) return cleanup(fail(PT_ERR_DEVICE, "setting up the component-wise leaves failed"));
+                s->use_leafwise = true;
+                s->d.leafwise_nodes = (const char*)s->d_leafwise;
+                s->d.soa = (const float*)((const char*)s->d_leafwise + nodes_b);
+                s->d.leafwise_root = lw.root;
+            }
+        }
+    }
     s->d.q_off = (uint32_t)q_off;
     s->d.q_root = with_q ? qn.root : PT_REF_NONE;
     s->d.q_root_exact = PT_Q_EXACT_BASE + flat->root_ref;
@@ -1595,6 +1972,7 @@ void pt_scene_destroy(pt_scene* s) {
     for (auto e : s->free_events) (void)hipEventDestroy(e);
     if (s->d_geom) (void)hipFree(s->d_geom);
     if (s->d_shade) (void)hipFree(s->d_shade);
+    if (s->d_leafwise) (void)hipFree(s->d_leafwise);
     if (s->d_small) (void)hipFree(s->d_small);
     if (s->d_spill) (void)hipFree(s->d_spill);
     if (s->d_spill2) (void)hipFree(s->d_spill2);
@@ -1644,7 +2022,11 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : MODE == TRACE_SHADOW_EXACT ? PT_KERNEL_SHADOW_EXACT : PT_KERNEL_SHADOW, here.stream);
     constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
     const dim3 grid(trace_grid(s, ANY));
-    if (MODE == TRACE_SHADOW_ANY && s->use_dense) {
+    if (ANY && s->use_leafwise) {
+        constexpr int LMODE = ANY ? MODE : TRACE_SHADOW_ANY;   /* (keeps the closest-hit instantiations of this function valid) */
+        hipLaunchKernelGGL(k_shadow_leafwise<LMODE>, dim3(s->grid_leafwise), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    }
+    else if (MODE == TRACE_SHADOW_ANY && s->use_dense) {
         hipLaunchKernelGGL(k_shadow_dense<DENSE_RAYS_PER_LANE>, dim3(s->grid_dense), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
     }
     else if (ANY && s->use_qnodes) {
@@ -1685,12 +2067,17 @@ static int init_trace_launch(pt_scene* s) {
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_d = v; }
     per_cu_d = std::max(1, std::min(per_cu_d, 8));
     s->grid_dense = std::max(8, (s->num_cus * per_cu_d) & ~7);
+    int per_cu_l = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_shadow_leafwise<TRACE_SHADOW_ANY>, TRACE_BLOCK, 0));
+    if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_l = v; }
+    per_cu_l = std::max(1, std::min(per_cu_l, 8));
+    s->grid_leafwise = std::max(8, (s->num_cus * per_cu_l) & ~7);
     per_cu_c = std::max(1, std::min(per_cu_c, 8));
     per_cu_a = std::max(1, std::min(per_cu_a, 8));
     /* a multiple of 8: the kernels deal their queue to the 8 XCDs by workgroup number */
     s->grid_closest = std::max(8, (s->num_cus * per_cu_c) & ~7);
     s->grid_any = std::max(8, (s->num_cus * per_cu_a) & ~7);
-    size_t threads = (size_t)std::max(std::max(s->grid_closest, s->grid_any), s->grid_dense) * TRACE_BLOCK;
+    size_t threads = (size_t)std::max(std::max(std::max(s->grid_closest, s->grid_any), s->grid_dense), s->grid_leafwise) * TRACE_BLOCK;
     size_t words = threads * (size_t)(STACK_MAX_CLOSEST - STACK_LDS);
     s->spill_bytes = words * sizeof(uint32_t);
     HIP_TRY(hipMalloc((void**)&s->d_spill, s->spill_bytes));

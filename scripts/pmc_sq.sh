@@ -14,5 +14,5 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   i=$((i+1))
   timeout -s KILL 240 rocprofv3 --pmc $grp -d $OUT/g$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --strong-spp 0 $EXTRA > $OUT/g$i.log 2>&1 || echo "group $i ($grp) failed" >> $OUT/failed.txt
 done
-python3 scripts/rocpd_summary.py $OUT --kernels k_trace,k_shadow_dense > $OUT/summary.txt
+python3 scripts/rocpd_summary.py $OUT --kernels k_trace,k_shadow_dense,k_shadow_leafwise > $OUT/summary.txt
 [ "${KEEP_DB:-0}" = "1" ] || find $OUT -name "*.db" -delete

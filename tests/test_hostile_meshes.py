@@ -90,9 +90,10 @@ def test_host_tree_and_lane_walk(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MESH_NAMES)
-@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW"])
+@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW", "PT_LEAFWISE"])
 def test_gpu_matches_oracle(name, option, monkeypatch):
-    """option: the any-hit walks on quantised interior nodes, or with deferred dense triangle tests."""
+    """option: the any-hit walks on quantised interior nodes, with deferred dense triangle tests, or
+    with leaves tested by the whole wave."""
     tris, scale = hostile_meshes()[name]
     host = pta.HostScene(tris)
     oracle = orc.Scene(tris)
