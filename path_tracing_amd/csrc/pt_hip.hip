@@ -219,6 +219,115 @@ struct TraceArgs {
     uint32_t* spill;         /* stack spill area: (STACK_MAX - STACK_LDS) * threads-in-grid dwords */
 };
 
+/* ---- leaves tested by the whole wave (k_trace<MODE, 0>, k_shadow_leafwise): see k_shadow_leafwise ---- */
+#ifndef LEAFWISE_WAVES_PER_EU
+#define LEAFWISE_WAVES_PER_EU 6
+#endif
+#define LEAFWISE_PIECE 64u                         /* triangles per piece = lanes */
+#define LEAFWISE_PIECE_WORDS (9u * LEAFWISE_PIECE)
+#define LEAFWISE_MAX_COUNT 255u
+#define LEAFWISE_MAX_PIECES (1u << 22)
+
+struct LeafPiece {            /* wave-uniform: one piece (up to 64 triangles) of one pending leaf */
+    uint64_t rest;            /* lanes whose leaves come after this one */
+    uint32_t lane;            /* the owner */
+    uint32_t piece;           /* its number in the pool */
+    uint32_t left;            /* triangles of the leaf from this piece on */
+    uint32_t valid;
+    uint32_t dead;            /* the owner has its hit: the leaf's remaining pieces are not tested */
+};
+
+/* The piece after `p` in the round's sequence: the next 64 triangles of the same leaf, else the
+ * leaf of the next lane in `rest`. */
+__device__ __forceinline__ void leaf_piece_next(LeafPiece& p, uint32_t cur) {
+    if (p.valid && p.left > LEAFWISE_PIECE) { p.left -= LEAFWISE_PIECE; p.piece += 1u; return; }
+    if (p.rest == 0ull) { p.valid = 0u; return; }
+    const uint32_t b = (uint32_t)__builtin_ctzll(p.rest);
+    p.rest &= p.rest - 1ull;
+    const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)b);
+    p.lane = b;
+    p.left = ref & 255u;
+    p.piece = (ref >> 8) & (LEAFWISE_MAX_PIECES - 1u);
+    p.valid = 1u;
+    p.dead = 0u;
+}
+
+struct Tri9 { float p0x, p0y, p0z, e1x, e1y, e1z, e2x, e2y, e2z; };
+
+/* Lane j of the wave asks for triangle j of the piece (lanes past the leaf's end repeat its last
+ * triangle): one scalar base, one 32-bit lane offset, nine constant row offsets. */
+__device__ __forceinline__ void leaf_piece_load(const LeafPiece& p, const float* __restrict__ soa, uint32_t lane, Tri9& t) {
+    if (!p.valid) return;
+    const uint32_t j = lane < p.left ? lane : p.left - 1u;
+    const char* rows = (const char*)soa + (size_t)p.piece * (LEAFWISE_PIECE_WORDS * 4u) + j * 4u;
+    t.p0x = *(const float*)(rows);
+    t.p0y = *(const float*)(rows + 1u * LEAFWISE_PIECE * 4u);
+    t.p0z = *(const float*)(rows + 2u * LEAFWISE_PIECE * 4u);
+    t.e1x = *(const float*)(rows + 3u * LEAFWISE_PIECE * 4u);
+    t.e1y = *(const float*)(rows + 4u * LEAFWISE_PIECE * 4u);
+    t.e1z = *(const float*)(rows + 5u * LEAFWISE_PIECE * 4u);
+    t.e2x = *(const float*)(rows + 6u * LEAFWISE_PIECE * 4u);
+    t.e2y = *(const float*)(rows + 7u * LEAFWISE_PIECE * 4u);
+    t.e2z = *(const float*)(rows + 8u * LEAFWISE_PIECE * 4u);
+}
+
+/* One piece against its owner's ray; the owner takes the outcome. */
+template <int MODE>
+__device__ __forceinline__ void leaf_piece_test(LeafPiece& now, const Tri9& t, Lane& L, uint32_t lane) {
+    /* the whole set is waited for here, along every path (the test below reads some of its words only
+     * behind its early exits): afterwards the set can be loaded anew without waiting for the other one */
+    asm volatile("" :: "v"(t.p0x), "v"(t.p0y), "v"(t.p0z), "v"(t.e1x), "v"(t.e1y), "v"(t.e1z), "v"(t.e2x), "v"(t.e2y), "v"(t.e2z));
+    if (now.dead) return;
+    const int b = (int)now.lane;
+    Ray9 r;
+    r.ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.ox), b));
+    r.oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.oy), b));
+    r.oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.oz), b));
+    r.dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dx), b));
+    r.dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dy), b));
+    r.dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dz), b));
+    r.rx = 0.0f; r.ry = 0.0f; r.rz = 0.0f;   /* the triangle test does not use the reciprocals */
+    /* any-hit: a hit counts if it is nearer than the best so far (kdtree.cpp:286): +inf, or the light's distance */
+    const float bound = MODE == TRACE_SHADOW_BOUNDED ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.best.t), b)) : pt_inf();
+    TriData tr;
+    tr.p0x = t.p0x; tr.p0y = t.p0y; tr.p0z = t.p0z;
+    tr.e1x = t.e1x; tr.e1y = t.e1y; tr.e1z = t.e1z;
+    tr.e2x = t.e2x; tr.e2y = t.e2y; tr.e2z = t.e2z;
+    tr.mesh_index = 0u; tr.leaf_remaining = 0u;
+    float tt = 0.0f, uu = 0.0f, vv = 0.0f;
+    constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
+    const bool mine = lane == now.lane;
+    const bool last = now.left <= LEAFWISE_PIECE;
+    if (ANY) {
+        const bool hit = lane < now.left && tri_hit(tr, r, tt, uu, vv) && tt < bound;
+        const bool any = __ballot(hit) != 0ull;
+        /* written as selects: the owner's state stays in registers */
+        L.found = L.found || (mine && any);
+        L.cur = (mine && (any || last)) ? PT_REF_NONE : L.cur;
+        L.sp = (mine && any) ? 0 : L.sp;
+        if (any) now.dead = 1u;
+    } else {
+        /* the hits of the piece reach the owner in triangle order, each with the two strict
+         * comparisons of the reference's loop (kdtree.cpp:281-293): a nearer hit replaces the best, an
+         * equally near one does not */
+        const bool hit = lane < now.left && tri_hit(tr, r, tt, uu, vv);
+        uint64_t hm = __ballot(hit);
+        while (hm) {
+            const int h = __builtin_ctzll(hm);
+            hm &= hm - 1ull;
+            const float th = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt), h));
+            const float uh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uu), h));
+            const float vh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), h));
+            const bool better = mine && th < L.best.t;
+            L.best.t = better ? th : L.best.t; L.best.u = better ? uh : L.best.u; L.best.v = better ? vh : L.best.v;
+            L.best.tri = better ? ((now.piece << 6) | (uint32_t)h) : L.best.tri;   /* piece and slot: see k_leafwise_positions */
+            L.found = L.found || better;
+            L.local = (mine && th < L.local) ? th : L.local;
+        }
+        L.cur = (mine && last) ? PT_REF_NONE : L.cur;
+    }
+}
+
 /*
  * Persistent trace kernel.  Every wave loops over "rounds"; in a round each lane that holds a
  * ray advances it by one step of the lane state machine (traverse_core.h): one triangle of its
@@ -241,8 +350,12 @@ struct TraceArgs {
  * lane is idle, so the grid always drains.
  */
 template <int MODE, int TPR = 1, bool QN = false>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 1 ? TRACE_WAVES_PER_EU : TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU_3))) void k_trace(DScene sc, TraceArgs a) {
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 0 ? LEAFWISE_WAVES_PER_EU : TPR == 1 ? TRACE_WAVES_PER_EU : TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU_3))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED);
+    /* TPR = 0: a lane does not walk its leaf; the wave tests it in the next round (see
+     * k_shadow_leafwise).  Hits are then named by piece and slot, k_leafwise_positions translates. */
+    constexpr bool COOP = TPR == 0;
+    static_assert(!(COOP && QN), "the leafwise walk reads exact node records");
     /* QN: interior nodes whose children are both interior are read as 32-byte quantised records (two
      * load pieces instead of four); any-hit walks only, whose answer does not depend on which
      * enclosing boxes the interior levels are tested against (traverse_core.h "q-nodes") */
@@ -313,6 +426,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
     int rec_more = 0;                         /* records loaded after the lane's triangle */
     bool starting = false;                    /* this lane's registers are receiving a new ray */
     uint32_t new_ray = 0;
+    /* COOP: the lanes that held a leaf when the previous round ended, the piece the next load is for,
+     * and the two register sets the pieces alternate between */
+    uint64_t pending = 0ull;
+    LeafPiece ahead;
+    ahead.rest = 0ull; ahead.lane = 0u; ahead.piece = 0u; ahead.left = 1u; ahead.valid = 0u; ahead.dead = 0u;
+    Tri9 ta, tb;
+    ta.p0x = ta.p0y = ta.p0z = ta.e1x = ta.e1y = ta.e1z = ta.e2x = ta.e2y = ta.e2z = 0.0f;
+    tb = ta;
 
     while (true) {
         /* The round's single wait: every register a load of the previous round may have targeted
@@ -326,6 +447,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             asm volatile("" :: "v"(qx[k][0].x), "v"(qx[k][0].y), "v"(qx[k][0].z), "v"(qx[k][0].w), "v"(qx[k][1].x), "v"(qx[k][1].y), "v"(qx[k][1].z),
                                "v"(qx[k][1].w), "v"(qx[k][2].x), "v"(qx[k][2].y), "v"(qx[k][2].w));
 
+        if (COOP) {
+            asm volatile("" :: "v"(ta.p0x), "v"(ta.p0y), "v"(ta.p0z), "v"(ta.e1x), "v"(ta.e1y), "v"(ta.e1z), "v"(ta.e2x), "v"(ta.e2y), "v"(ta.e2z));
+            asm volatile("" :: "v"(tb.p0x), "v"(tb.p0y), "v"(tb.p0z), "v"(tb.e1x), "v"(tb.e1y), "v"(tb.e1z), "v"(tb.e2x), "v"(tb.e2y), "v"(tb.e2z));
+            /* ---- the leaves that were pending when the previous round ended, piece by piece: pieces
+             * alternate between the two register sets, the first of a round in `ta`; when a set has
+             * been tested, the piece after the one in the other set is loaded into it ---- */
+            if (pending) {
+                LeafPiece now;
+                now.rest = pending; now.lane = 0u; now.piece = 0u; now.left = 1u; now.valid = 0u; now.dead = 0u;
+                leaf_piece_next(now, L.cur);
+                while (true) {
+                    leaf_piece_test<MODE>(now, ta, L, lane);
+                    leaf_piece_next(ahead, L.cur);
+                    leaf_piece_load(ahead, sc.soa, lane, ta);
+                    leaf_piece_next(now, L.cur);
+                    if (!now.valid) break;
+                    leaf_piece_test<MODE>(now, tb, L, lane);
+                    leaf_piece_next(ahead, L.cur);
+                    leaf_piece_load(ahead, sc.soa, lane, tb);
+                    leaf_piece_next(now, L.cur);
+                    if (!now.valid) break;
+                }
+            }
+        }
+
         /* ---- start the refilled lanes (they take their first record with everyone else below) ---- */
         bool defer = false;
         if (starting) {
@@ -337,7 +483,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
                 ray_set_recip(L.r);
                 /* with q-nodes every node position is in their numbering; rays that are not tame start
                  * on the exact root and stay on exact records */
-                const uint32_t root_pos = QN ? ((scene_tame && ray_is_tame(L.r)) ? sc.q_root : sc.q_root_exact) : sc.root_ref;
+                const uint32_t root_pos = COOP ? sc.leafwise_root : QN ? ((scene_tame && ray_is_tame(L.r)) ? sc.q_root : sc.q_root_exact) : sc.root_ref;
                 lane_start(L, root_pos, sc.root, scene_tame);
                 /* a triangle counts only if it is strictly nearer than the best so far: starting
                  * from the bound instead of infinity makes that "nearer than the light" */
@@ -357,7 +503,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
         const bool active = ray >= 0;
 
         /* ---- one step per lane that has its record ---- */
-        if (rec_tri) {
+        if (!COOP && rec_tri) {
             TriData tr;
             tr.p0x = q0.x; tr.p0y = q0.y; tr.p0z = q0.z;
             tr.e1x = q0.w; tr.e1y = q1.x; tr.e1z = q1.y;
@@ -420,14 +566,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
         /* ---- next round's records (one load site: a second one for the lanes that know their
          * record before the pops would make the compiler wait for the first, since both target
          * the same registers) ---- */
-        rec_tri = active && lane_has_leaf(L);
+        rec_tri = !COOP && active && lane_has_leaf(L);
         rec_node = active && lane_has_node(L);
         if (rec_tri || rec_node) {
             const bool rec_exact = !QN || L.cur >= PT_Q_EXACT_BASE;   /* (for a node) an exact 64-byte record */
             const uint32_t off = rec_tri ? sc.tris_off + lane_leaf_pos(L) * (uint32_t)sizeof(pt_tri_isect)
                                : !QN ? L.cur * (uint32_t)sizeof(pt_flat_node)
                                : rec_exact ? (L.cur - PT_Q_EXACT_BASE) * (uint32_t)sizeof(pt_flat_node) : sc.q_off + L.cur * 32u;
-            const float4* rec = (const float4*)(sc.geom + off);
+            const float4* rec = (const float4*)((COOP ? sc.leafwise_nodes : sc.geom) + off);
             q0 = rec[0]; q1 = rec[1];
             if (!QN || rec_tri || rec_exact) q2 = rec[2];
             if (rec_node && rec_exact) q3 = rec[3];
@@ -440,6 +586,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             }
         }
 
+        if (COOP) {   /* the first two pieces of the leaves now pending */
+            pending = __ballot(active && lane_has_leaf(L));
+            ahead.rest = pending; ahead.valid = 0u;
+            leaf_piece_next(ahead, L.cur);
+            leaf_piece_load(ahead, sc.soa, lane, ta);
+            leaf_piece_next(ahead, L.cur);
+            leaf_piece_load(ahead, sc.soa, lane, tb);
+        }
+
         /* ---- retire finished rays ---- */
         if (active && lane_finished(L)) {
             const uint32_t i = (uint32_t)ray;
@@ -450,7 +605,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
                     h.y = L.found ? L.best.t : 0.0f; h.z = L.found ? L.best.u : 0.0f; h.w = L.found ? L.best.v : 0.0f;
                     a.out_hit[i] = h;
                 } else {
-                    a.out_idx[i] = L.found ? (int32_t)L.best.mesh : -1;
+                    a.out_idx[i] = L.found ? (int32_t)(COOP ? L.best.tri : L.best.mesh) : -1;
                     a.out_t[i] = L.found ? L.best.t : 0.0f;
                     a.out_u[i] = L.found ? L.best.u : 0.0f;
                     a.out_v[i] = L.found ? L.best.v : 0.0f;
@@ -904,92 +1059,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(NW 
  * leaf meets the same triangle test, so "hit or not" is k_trace's.  Leaf references on the device are
  * PT_REF_LEAF | first piece << 8 | count (count <= 255) in a copy of the node array made for this kernel.
  */
-#ifndef LEAFWISE_WAVES_PER_EU
-#define LEAFWISE_WAVES_PER_EU 6
-#endif
-#define LEAFWISE_PIECE 64u                         /* triangles per piece = lanes */
-#define LEAFWISE_PIECE_WORDS (9u * LEAFWISE_PIECE)
-#define LEAFWISE_MAX_COUNT 255u
-#define LEAFWISE_MAX_PIECES (1u << 22)
-
-struct LeafPiece {            /* wave-uniform: one piece (up to 64 triangles) of one pending leaf */
-    uint64_t rest;            /* lanes whose leaves come after this one */
-    uint32_t lane;            /* the owner */
-    uint32_t piece;           /* its number in the pool */
-    uint32_t left;            /* triangles of the leaf from this piece on */
-    uint32_t valid;
-    uint32_t dead;            /* the owner has its hit: the leaf's remaining pieces are not tested */
-};
-
-/* The piece after `p` in the round's sequence: the next 64 triangles of the same leaf, else the
- * leaf of the next lane in `rest`. */
-__device__ __forceinline__ void leaf_piece_next(LeafPiece& p, uint32_t cur) {
-    if (p.valid && p.left > LEAFWISE_PIECE) { p.left -= LEAFWISE_PIECE; p.piece += 1u; return; }
-    if (p.rest == 0ull) { p.valid = 0u; return; }
-    const uint32_t b = (uint32_t)__builtin_ctzll(p.rest);
-    p.rest &= p.rest - 1ull;
-    const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)b);
-    p.lane = b;
-    p.left = ref & 255u;
-    p.piece = (ref >> 8) & (LEAFWISE_MAX_PIECES - 1u);
-    p.valid = 1u;
-    p.dead = 0u;
-}
-
-struct Tri9 { float p0x, p0y, p0z, e1x, e1y, e1z, e2x, e2y, e2z; };
-
-/* Lane j of the wave asks for triangle j of the piece (lanes past the leaf's end repeat its last
- * triangle): one scalar base, one 32-bit lane offset, nine constant row offsets. */
-__device__ __forceinline__ void leaf_piece_load(const LeafPiece& p, const float* __restrict__ soa, uint32_t lane, Tri9& t) {
-    if (!p.valid) return;
-    const uint32_t j = lane < p.left ? lane : p.left - 1u;
-    const char* rows = (const char*)soa + (size_t)p.piece * (LEAFWISE_PIECE_WORDS * 4u) + j * 4u;
-    t.p0x = *(const float*)(rows);
-    t.p0y = *(const float*)(rows + 1u * LEAFWISE_PIECE * 4u);
-    t.p0z = *(const float*)(rows + 2u * LEAFWISE_PIECE * 4u);
-    t.e1x = *(const float*)(rows + 3u * LEAFWISE_PIECE * 4u);
-    t.e1y = *(const float*)(rows + 4u * LEAFWISE_PIECE * 4u);
-    t.e1z = *(const float*)(rows + 5u * LEAFWISE_PIECE * 4u);
-    t.e2x = *(const float*)(rows + 6u * LEAFWISE_PIECE * 4u);
-    t.e2y = *(const float*)(rows + 7u * LEAFWISE_PIECE * 4u);
-    t.e2z = *(const float*)(rows + 8u * LEAFWISE_PIECE * 4u);
-}
-
-/* One piece against its owner's ray; the owner takes the outcome. */
-template <int MODE>
-__device__ __forceinline__ void leaf_piece_test(LeafPiece& now, const Tri9& t, Lane& L, uint32_t lane) {
-    /* the whole set is waited for here, along every path (the test below reads some of its words only
-     * behind its early exits): afterwards the set can be loaded anew without waiting for the other one */
-    asm volatile("" :: "v"(t.p0x), "v"(t.p0y), "v"(t.p0z), "v"(t.e1x), "v"(t.e1y), "v"(t.e1z), "v"(t.e2x), "v"(t.e2y), "v"(t.e2z));
-    if (now.dead) return;
-    const int b = (int)now.lane;
-    Ray9 r;
-    r.ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.ox), b));
-    r.oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.oy), b));
-    r.oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.oz), b));
-    r.dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dx), b));
-    r.dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dy), b));
-    r.dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.r.dz), b));
-    r.rx = 0.0f; r.ry = 0.0f; r.rz = 0.0f;   /* the triangle test does not use the reciprocals */
-    /* a hit counts if it is nearer than the best so far (kdtree.cpp:286): +inf, or the light's distance */
-    const float bound = MODE == TRACE_SHADOW_BOUNDED ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.best.t), b)) : pt_inf();
-    TriData tr;
-    tr.p0x = t.p0x; tr.p0y = t.p0y; tr.p0z = t.p0z;
-    tr.e1x = t.e1x; tr.e1y = t.e1y; tr.e1z = t.e1z;
-    tr.e2x = t.e2x; tr.e2y = t.e2y; tr.e2z = t.e2z;
-    tr.mesh_index = 0u; tr.leaf_remaining = 0u;
-    float tt, uu, vv;
-    const bool hit = lane < now.left && tri_hit(tr, r, tt, uu, vv) && tt < bound;
-    const bool any = __ballot(hit) != 0ull;
-    const bool last = now.left <= LEAFWISE_PIECE;
-    /* written as selects: the owner's state stays in registers */
-    const bool mine = lane == now.lane;
-    L.found = L.found || (mine && any);
-    L.cur = (mine && (any || last)) ? PT_REF_NONE : L.cur;
-    L.sp = (mine && any) ? 0 : L.sp;
-    if (any) now.dead = 1u;
-}
-
 template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(LEAFWISE_WAVES_PER_EU))) void k_shadow_leafwise(DScene sc, TraceArgs a) {
     static_assert(MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED, "any-hit walks only");
@@ -1647,10 +1716,31 @@ __global__ __launch_bounds__(256) void k_leafwise_fill(const uint32_t* __restric
     }
 }
 
+/* Closest hits of the leafwise walk name their triangle by piece and slot (piece << 6 | slot); the
+ * rest of the library wants its position in the triangle arrays (FLAT: the word in out_hit) or its
+ * index in the caller's mesh (MESH: out_idx). */
+__global__ __launch_bounds__(256) void k_leafwise_positions(const uint32_t* __restrict__ d_count, uint32_t count_mul, float4* hit, int32_t* idx,
+                                                             const uint32_t* __restrict__ piece_start, const uint32_t* __restrict__ tris) {
+    const uint32_t n = *d_count * count_mul;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        if (hit) {
+            const uint32_t slot = __float_as_uint(hit[i].x);
+            if (slot != 0xffffffffu) hit[i].x = __uint_as_float(piece_start[slot >> 6] + (slot & 63u));
+        } else {
+            const int32_t slot = idx[i];
+            if (slot >= 0) {
+                const uint32_t pos = piece_start[(uint32_t)slot >> 6] + ((uint32_t)slot & 63u);
+                idx[i] = (int32_t)tris[(size_t)pos * (sizeof(pt_tri_isect) / 4) + offsetof(pt_tri_isect, mesh_index) / 4];
+            }
+        }
+    }
+}
+
 /* Host part: the node records with their leaf references rewritten, and where each leaf goes. */
 struct LeafwiseBuild {
     std::vector<pt_flat_node> nodes;
     std::vector<uint32_t> start, piece, count;
+    std::vector<uint32_t> piece_start;   /* per piece: position of its first triangle in the triangle arrays */
     uint32_t root = PT_REF_NONE;
     uint64_t pieces = 0;
     bool ok = true;
@@ -1668,6 +1758,7 @@ static void leafwise_build(const pt_flat_scene* f, LeafwiseBuild& out) {
         out.pieces += (count + LEAFWISE_PIECE - 1) / LEAFWISE_PIECE;
         if (out.pieces > LEAFWISE_MAX_PIECES) { out.ok = false; return ref; }
         out.start.push_back(start); out.piece.push_back((uint32_t)g); out.count.push_back(count);
+        for (uint32_t k = 0; k < count; k += LEAFWISE_PIECE) out.piece_start.push_back(start + k);
         return PT_REF_LEAF | ((uint32_t)g << 8) | count;
     };
     out.root = convert(f->root_ref);
@@ -1696,7 +1787,9 @@ struct pt_scene {
     void* d_shade = nullptr;
     void* d_leafwise = nullptr;   /* k_shadow_leafwise: rewritten node records, then the triangles by component */
     bool use_leafwise = false;
-    int grid_leafwise = 0;
+    int leafwise_mode = 0;        /* PT_LEAFWISE: 1 any-hit walks (k_shadow_leafwise), 2 every walk (k_trace<MODE, 0>), 3 both */
+    uint32_t* d_piece_start = nullptr;   /* inside d_leafwise */
+    int grid_leafwise = 0, grid_leafwise_closest = 0;
     uint64_t n_tris = 0;
     uint32_t* d_small = nullptr; /* raycast entry points: [0] ray count, [1] deferred count, two sets of queue heads at SMALL_HEADS0/1 */
     uint32_t* d_spill = nullptr; /* stack spill area shared by all trace launches on the stream */
@@ -1903,16 +1996,19 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
      * at most 255 triangles. */
     s->use_leafwise = false;
     if (const char* e = getenv("PT_LEAFWISE")) {
-        if (atoi(e) == 1 && flat->n_tris > 0) {
+        if (atoi(e) >= 1 && atoi(e) <= 3 && flat->n_tris > 0) {
             LeafwiseBuild lw;
             leafwise_build(flat, lw);
             if (lw.ok) {
                 const size_t nodes_b = (std::max<size_t>(flat->n_nodes, 1) * sizeof(pt_flat_node) + 255) & ~(size_t)255;
                 const size_t soa_b = std::max<uint64_t>(lw.pieces, 1) * LEAFWISE_PIECE_WORDS * sizeof(float);
                 const size_t nl = lw.start.size();
+                const size_t ps_b = std::max<size_t>(lw.piece_start.size(), 1) * sizeof(uint32_t);
                 uint32_t* d_tab = nullptr;
-                bool good = hipMalloc(&s->d_leafwise, nodes_b + soa_b) == hipSuccess && hipMalloc((void**)&d_tab, std::max<size_t>(nl, 1) * 12) == hipSuccess;
+                bool good = hipMalloc(&s->d_leafwise, nodes_b + soa_b + ps_b) == hipSuccess && hipMalloc((void**)&d_tab, std::max<size_t>(nl, 1) * 12) == hipSuccess;
                 good = good && hipMemset((char*)s->d_leafwise + nodes_b, 0, soa_b) == hipSuccess;
+                if (good && !lw.piece_start.empty())
+                    good = hipMemcpy((char*)s->d_leafwise + nodes_b + soa_b, lw.piece_start.data(), lw.piece_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
                 if (good && flat->n_nodes) good = hipMemcpy(s->d_leafwise, lw.nodes.data(), flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
                 if (good && nl) {
                     good = hipMemcpy(d_tab, lw.start.data(), nl * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -1928,6 +2024,8 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
                 if (d_tab) (void)hipFree(d_tab);
                 if (!good) return cleanup(fail(PT_ERR_DEVICE, "setting up the component-wise leaves failed"));
                 s->use_leafwise = true;
+                s->leafwise_mode = atoi(e);
+                s->d_piece_start = (uint32_t*)((char*)s->d_leafwise + nodes_b + soa_b);
                 s->d.leafwise_nodes = (const char*)s->d_leafwise;
                 s->d.soa = (const float*)((const char*)s->d_leafwise + nodes_b);
                 s->d.leafwise_root = lw.root;
@@ -2022,9 +2120,18 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : MODE == TRACE_SHADOW_EXACT ? PT_KERNEL_SHADOW_EXACT : PT_KERNEL_SHADOW, here.stream);
     constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
     const dim3 grid(trace_grid(s, ANY));
-    if (ANY && s->use_leafwise) {
+    if (ANY && s->use_leafwise && s->leafwise_mode != 2) {
         constexpr int LMODE = ANY ? MODE : TRACE_SHADOW_ANY;   /* (keeps the closest-hit instantiations of this function valid) */
         hipLaunchKernelGGL(k_shadow_leafwise<LMODE>, dim3(s->grid_leafwise), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+    }
+    else if (s->use_leafwise && s->leafwise_mode >= 2) {
+        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(ANY ? s->grid_leafwise : s->grid_leafwise_closest), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+        if (MODE == TRACE_CLOSEST_FLAT || MODE == TRACE_CLOSEST_MESH) {
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_leafwise_positions, dim3((unsigned)std::max(8, s->num_cus * 8)), dim3(256), 0, here.stream, a.d_count, a.count_mul,
+                               MODE == TRACE_CLOSEST_FLAT ? a.out_hit : (float4*)nullptr, MODE == TRACE_CLOSEST_MESH ? a.out_idx : (int32_t*)nullptr,
+                               (const uint32_t*)s->d_piece_start, (const uint32_t*)(s->d.geom + s->d.tris_off));
+        }
     }
     else if (MODE == TRACE_SHADOW_ANY && s->use_dense) {
         hipLaunchKernelGGL(k_shadow_dense<DENSE_RAYS_PER_LANE>, dim3(s->grid_dense), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
@@ -2072,12 +2179,17 @@ static int init_trace_launch(pt_scene* s) {
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_l = v; }
     per_cu_l = std::max(1, std::min(per_cu_l, 8));
     s->grid_leafwise = std::max(8, (s->num_cus * per_cu_l) & ~7);
+    int per_cu_lc = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lc, k_trace<TRACE_CLOSEST_FLAT, 0>, TRACE_BLOCK, 0));
+    if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_lc = v; }
+    per_cu_lc = std::max(1, std::min(per_cu_lc, 8));
+    s->grid_leafwise_closest = std::max(8, (s->num_cus * per_cu_lc) & ~7);
     per_cu_c = std::max(1, std::min(per_cu_c, 8));
     per_cu_a = std::max(1, std::min(per_cu_a, 8));
     /* a multiple of 8: the kernels deal their queue to the 8 XCDs by workgroup number */
     s->grid_closest = std::max(8, (s->num_cus * per_cu_c) & ~7);
     s->grid_any = std::max(8, (s->num_cus * per_cu_a) & ~7);
-    size_t threads = (size_t)std::max(std::max(std::max(s->grid_closest, s->grid_any), s->grid_dense), s->grid_leafwise) * TRACE_BLOCK;
+    size_t threads = (size_t)std::max(std::max(std::max(s->grid_closest, s->grid_any), s->grid_dense), std::max(s->grid_leafwise, s->grid_leafwise_closest)) * TRACE_BLOCK;
     size_t words = threads * (size_t)(STACK_MAX_CLOSEST - STACK_LDS);
     s->spill_bytes = words * sizeof(uint32_t);
     HIP_TRY(hipMalloc((void**)&s->d_spill, s->spill_bytes));

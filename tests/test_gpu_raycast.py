@@ -420,10 +420,15 @@ def test_wave_wide_leaf_tests(scene_small, scene_medium, monkeypatch):
     monkeypatch.setenv("PT_LEAFWISE", "1")
     wide = {id(sc): pta.GpuScene(sc.host, 0) for sc in (scene_small, scene_medium)}
     stacked_gpu = pta.GpuScene(stacked_host, 0)
+    # =2: every walk, the closest-hit ones included
+    monkeypatch.setenv("PT_LEAFWISE", "2")
+    all_walks = [(pta.GpuScene(sc.host, 0), sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(pta.GpuScene(stacked_host, 0), stacked_oracle, stacked)]
     monkeypatch.delenv("PT_LEAFWISE")
-    cases = [(wide[id(sc)], sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(stacked_gpu, stacked_oracle, stacked)]
+    cases = [(wide[id(sc)], sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(stacked_gpu, stacked_oracle, stacked)] + all_walks
     for g, oracle, tris in cases:
         for name, (o, d) in all_ray_sets(tris, 20000).items():
+            if any(g is w[0] for w in all_walks):
+                assert_hits_equal(g.raycast_closest(o, d), oracle.raycast(o, d), name + " closest")
             dist = np.where(rng.random(len(o)) < 0.3, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
             assert np.array_equal(g.raycast_shadow(o, d, dist), oracle.shadow_visible(o, d, dist)), name
             idx, t, _, _ = oracle.raycast(o, d)
@@ -432,9 +437,10 @@ def test_wave_wide_leaf_tests(scene_small, scene_medium, monkeypatch):
             assert np.array_equal(g.raycast_shadow(o, d, bound, bounded=True), oracle.shadow_visible(o, d, bound, bounded=True)), name + " bounded"
     cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
     films = []
-    for g in (scene_medium.gpu, wide[id(scene_medium)]):
+    for g in (scene_medium.gpu, wide[id(scene_medium)], all_walks[1][0]):
         f = pta.Film(g, 320, 200)
         st = f.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 4)], seed=31)
         films.append((f.read(), (st.closest_rays, st.shadow_rays, st.shadow_rays_traced)))
-    assert films[0][1] == films[1][1]
-    assert np.array_equal(films[0][0][0].view(np.uint32), films[1][0][0].view(np.uint32)) and np.array_equal(films[0][0][1], films[1][0][1])
+    for other in films[1:]:
+        assert films[0][1] == other[1]
+        assert np.array_equal(films[0][0][0].view(np.uint32), other[0][0].view(np.uint32)) and np.array_equal(films[0][0][1], other[0][1])
