@@ -413,6 +413,10 @@ def main():
             key = "level%d_%dx%d" % (args.level, W, H) + ("_lambert" if args.lambertian else "")
             tr = measured_traffic(key)
 
+            variant = gpu.trace_variant()
+            # a lane's walk reads 48-byte triangle records; the wave-wide leaf tests read 36 bytes per triangle
+            tri_bytes = 36 if variant["leafwise"] else 48
+
             def price(name, cls, rays, nodes_per_ray, tris_per_ray, io_bytes, algorithmic_bytes):
                 """Roofline entry of one trace-kernel class from this run's event times."""
                 ms, launches = kt[cls]
@@ -420,15 +424,18 @@ def main():
                     return None
                 rays_per_launch = rays / launches
                 launch_s = ms / launches * 1e-3
-                loaded_per_ray = nodes_per_ray * 64 + tris_per_ray * 48 + io_bytes
+                loaded_per_ray = nodes_per_ray * 64 + tris_per_ray * tri_bytes + io_bytes
                 loaded = rays_per_launch * loaded_per_ray / launch_s / 1e9
-                e = {"kernel": name, "share_of_kernel_ms": round(ms / sum(v[0] for v in kt.values()), 4),
+                e = {"kernel": name, "trace_variant": variant, "share_of_kernel_ms": round(ms / sum(v[0] for v in kt.values()), 4),
                      "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(ms / launches, 4),
                      "node_records_per_ray": round(float(nodes_per_ray), 3), "tri_records_per_ray": round(float(tris_per_ray), 3),
                      "loaded_bytes_per_ray": round(float(loaded_per_ray), 1), "loaded_GBps": round(loaded, 2),
                      "frac_of_l2_gather_rate": round(loaded / L2_GATHER_PEAK_GBS, 5),
                      "frac_of_l2_aggregate": round(loaded / L2_AGGREGATE_GBS, 5),
                      "frac_of_own_microbenchmark": round(loaded / OWN_GATHER_RATE_GBS, 4)}
+                if variant["leafwise"]:
+                    e["triangle_count_note"] = ("triangles per ray as a lane's own walk meets them (an any-hit walk stops inside a leaf at its "
+                                                "first hit); the wave-wide tests fetch whole leaves, 36 bytes per triangle, so this is a lower bound")
                 if algorithmic_bytes is not None:
                     alg = rays_per_launch * algorithmic_bytes / launch_s / 1e9
                     e.update({"algorithmic_bytes_per_ray": round(float(algorithmic_bytes), 1), "algorithmic_GBps": round(alg, 2),

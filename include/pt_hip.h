@@ -183,6 +183,13 @@ int pt_scene_sync(pt_scene* s);
 #define PT_KERNEL_CLASSES    6
 int pt_scene_kernel_time(pt_scene* s, int kernel_class, int reset, double* ms, uint64_t* launches);
 
+/* Which trace kernels the scene's geometry selected (no counterpart in the reference; for
+ * measurement tools): out[0] triangles of a leaf a lane tests per round (1, 2, 3; 0 when leaves are
+ * tested by the whole wave from 36-byte component-wise records instead), out[1] 1 if the any-hit
+ * walks read quantised 32-byte interior nodes, out[2] 1 if the any-hit walk defers its triangle
+ * tests to dense passes, out[3] reserved (0). */
+int pt_scene_trace_variant(const pt_scene* s, int32_t out[4]);
+
 /* ---- film and rendering -------------------------------------------------------------- */
 
 /* The fields of Scene that Integrator::perform_pass reads at every pass

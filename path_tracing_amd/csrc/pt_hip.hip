@@ -219,7 +219,29 @@ struct TraceArgs {
     uint32_t* spill;         /* stack spill area: (STACK_MAX - STACK_LDS) * threads-in-grid dwords */
 };
 
-/* ---- leaves tested by the whole wave (k_trace<MODE, 0>, k_shadow_leafwise): see k_shadow_leafwise ---- */
+/*
+ * WAVE-WIDE leaf tests (k_trace<MODE, 0>), for scenes whose leaves are large (the reference caps its
+ * tree at 19 levels, kdtree.cpp:13, so tens of millions of triangles end up 40 to a leaf).
+ *
+ * In k_trace a lane walks its leaf alone, a few 48-byte records per round, each through per-lane
+ * addresses: on such scenes the kernels are bound by the rate at which the vector-memory path takes
+ * distinct lane addresses (asking a round early for the next round's lines, two more addresses per
+ * lane, made them 20 % slower).  Here a lane that reaches a leaf does not test it: in the next round
+ * the WAVE tests that leaf for it, one triangle per lane, from a copy of the triangles stored
+ * component by component in pieces of 64 (nine rows of 64 floats per piece, a leaf of more than 64
+ * triangles in consecutive pieces), so that a piece is fetched by nine loads of consecutive words at
+ * one scalar base -- a few dozen cache-line lookups instead of three per triangle -- and 36 instead
+ * of 48 bytes per triangle.  The pending leaves of a round are worked off one piece after the other,
+ * the loads of the next two pieces in flight; the ray is read from its owner's registers.
+ *
+ * Same results bit for bit: the same leaves are entered through the same box tests in the same order,
+ * and every triangle of an entered leaf meets the same triangle test.  An any-hit walk only asks
+ * whether any of them hits.  A closest-hit walk hands the hits of a piece to the owner in triangle
+ * order, each through the reference's two strict comparisons (kdtree.cpp:281-293), so the best hit and
+ * the leaf's nearest hit come out as from the lane's own loop; hits are named by piece and slot and
+ * translated afterwards (k_leafwise_positions).  Leaf references on the device are
+ * PT_REF_LEAF | first piece << 8 | count (count <= 255) in a copy of the node array made for these kernels.
+ */
 #ifndef LEAFWISE_WAVES_PER_EU
 #define LEAFWISE_WAVES_PER_EU 6
 #endif
@@ -227,6 +249,10 @@ struct TraceArgs {
 #define LEAFWISE_PIECE_WORDS (9u * LEAFWISE_PIECE)
 #define LEAFWISE_MAX_COUNT 255u
 #define LEAFWISE_MAX_PIECES (1u << 22)
+#ifndef LEAFWISE_MIN_AVERAGE_LEAF
+#define LEAFWISE_MIN_AVERAGE_LEAF 32u              /* triangles per leaf, on average, from which a scene gets these kernels
+                                                      (measured on MI355X: 41 per leaf +23 %, 10 per leaf -34 %, 5.6 per leaf -54 %) */
+#endif
 
 struct LeafPiece {            /* wave-uniform: one piece (up to 64 triangles) of one pending leaf */
     uint64_t rest;            /* lanes whose leaves come after this one */
@@ -352,8 +378,8 @@ __device__ __forceinline__ void leaf_piece_test(LeafPiece& now, const Tri9& t, L
 template <int MODE, int TPR = 1, bool QN = false>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR == 0 ? LEAFWISE_WAVES_PER_EU : TPR == 1 ? TRACE_WAVES_PER_EU : TPR == 2 ? TRACE_WAVES_PER_EU_2 : TRACE_WAVES_PER_EU_3))) void k_trace(DScene sc, TraceArgs a) {
     constexpr bool ANY = (MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED);
-    /* TPR = 0: a lane does not walk its leaf; the wave tests it in the next round (see
-     * k_shadow_leafwise).  Hits are then named by piece and slot, k_leafwise_positions translates. */
+    /* TPR = 0: a lane does not walk its leaf; the wave tests it in the next round ("WAVE-WIDE leaf
+     * tests" above).  Hits are then named by piece and slot, k_leafwise_positions translates. */
     constexpr bool COOP = TPR == 0;
     static_assert(!(COOP && QN), "the leafwise walk reads exact node records");
     /* QN: interior nodes whose children are both interior are read as 32-byte quantised records (two
@@ -1039,207 +1065,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(NW 
     }
 }
 
-/*
- * Any-hit walk with WAVE-WIDE leaf tests, for scenes whose leaves are large (the reference caps its
- * tree at 19 levels, kdtree.cpp:13, so tens of millions of triangles end up 40 to a leaf).
- *
- * In k_trace a lane walks its leaf alone, a few 48-byte records per round, each through per-lane
- * addresses: on such scenes the kernels are bound by the rate at which the vector-memory path takes
- * distinct lane addresses (asking a round early for the next round's lines, two more addresses per
- * lane, made them 20 % slower).  Here a lane that reaches a leaf does not test it: in the next round
- * the WAVE tests that leaf for it, one triangle per lane, from a copy of the triangles stored
- * component by component in pieces of 64 (nine rows of 64 floats per piece, a leaf of more than 64
- * triangles in consecutive pieces), so that a piece is fetched by nine loads of consecutive words at
- * one scalar base -- a few dozen cache-line lookups instead of three per triangle -- and 36 instead
- * of 48 bytes per triangle.  The pending leaves of a round are worked off one piece after the other,
- * the loads of the next two pieces in flight; the ray is read from its owner's registers.
- *
- * The answer of an any-hit walk does not depend on the order of the tests (traverse_core.h,
- * "q-nodes"): the same leaves are entered through the same box tests, every triangle of an entered
- * leaf meets the same triangle test, so "hit or not" is k_trace's.  Leaf references on the device are
- * PT_REF_LEAF | first piece << 8 | count (count <= 255) in a copy of the node array made for this kernel.
- */
-template <int MODE>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(LEAFWISE_WAVES_PER_EU))) void k_shadow_leafwise(DScene sc, TraceArgs a) {
-    static_assert(MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED, "any-hit walks only");
-    __shared__ uint32_t stk[(STACK_LDS + STACK_PAD) * TRACE_BLOCK];
-    const uint32_t n = *a.d_count * a.count_mul;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    LaneStack st;
-    st.lds = stk + STACK_PAD * TRACE_BLOCK + threadIdx.x;
-    st.stride = gridDim.x * TRACE_BLOCK;
-    st.spill = a.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
-
-    Lane L;
-    L.cur = PT_REF_NONE; L.sp = 0; L.found = false; L.frame_bits = 0; L.tame = true;
-    L.best.t = 0.0f; L.best.u = 0.0f; L.best.v = 0.0f; L.best.tri = 0u; L.best.mesh = 0u; L.local = 0.0f;
-    L.r.ox = L.r.oy = L.r.oz = 0.0f; L.r.dx = L.r.dy = L.r.dz = 0.0f; L.r.rx = L.r.ry = L.r.rz = 0.0f;
-    int32_t ray = -1;
-    uint32_t tgt = 0;
-    float dist = 0.0f;
-    uint32_t pool_next = 0, pool_end = 0;
-    bool exhausted = false;
-    const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / 64);
-    uint32_t chunk = TRACE_CHUNK;
-    while (chunk < TRACE_MAX_CHUNK_MUL * TRACE_CHUNK && (uint64_t)chunk * 2u * TRACE_MIN_CHUNKS_PER_WAVE * n_waves <= n) chunk *= 2u;
-    const uint32_t total_chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
-    bool first_chunk = true;
-    /* the queue is dealt to the XCDs as in k_trace */
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t xcd_waves = n_waves >> 3;
-    const uint32_t xcd_wave = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * (TRACE_BLOCK / 64) + (threadIdx.x >> 6));
-    uint32_t from_xcd = xcd, tried = 0;
-    const bool static_only = total_chunks <= (xcd_waves / TRACE_XCD_SUPER) * TRACE_XCD_SUPER * 8u;
-    const bool scene_tame = root_is_tame(sc.root);
-
-    float4 q0, q1, q2, q3;                    /* the lane's node record for this round */
-    q0 = q1 = q2 = q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    bool rec_node = false;
-    bool starting = false;
-    uint32_t new_ray = 0;
-    /* leaf pieces: the lanes that held a leaf when the previous round ended, the piece the next load
-     * is for, and the two register sets the pieces alternate between */
-    uint64_t pending = 0ull;
-    LeafPiece ahead;
-    ahead.rest = 0ull; ahead.lane = 0u; ahead.piece = 0u; ahead.left = 1u; ahead.valid = 0u; ahead.dead = 0u;
-    Tri9 ta, tb;
-    ta.p0x = ta.p0y = ta.p0z = ta.e1x = ta.e1y = ta.e1z = ta.e2x = ta.e2y = ta.e2z = 0.0f;
-    tb = ta;
-    uint32_t rounds = 0;
-
-    while (true) {
-        asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
-                           "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z));
-        asm volatile("" :: "v"(L.r.ox), "v"(L.r.oy), "v"(L.r.oz), "v"(L.r.dx), "v"(L.r.dy), "v"(L.r.dz), "v"(dist), "v"(tgt));
-        asm volatile("" :: "v"(ta.p0x), "v"(ta.p0y), "v"(ta.p0z), "v"(ta.e1x), "v"(ta.e1y), "v"(ta.e1z), "v"(ta.e2x), "v"(ta.e2y), "v"(ta.e2z));
-        asm volatile("" :: "v"(tb.p0x), "v"(tb.p0y), "v"(tb.p0z), "v"(tb.e1x), "v"(tb.e1y), "v"(tb.e1z), "v"(tb.e2x), "v"(tb.e2y), "v"(tb.e2z));
-        if (++rounds > (1u << 24)) break;   /* never reached: a wave's rounds are bounded by its rays' steps */
-
-        /* ---- the leaves that were pending when the previous round ended, piece by piece ----
-         * (a lane that is being refilled holds no leaf, and its old ray's registers are not read) */
-        if (pending) {
-            LeafPiece now;
-            now.rest = pending; now.lane = 0u; now.piece = 0u; now.left = 1u; now.valid = 0u; now.dead = 0u;
-            leaf_piece_next(now, L.cur);
-            /* pieces alternate between the two register sets, the first of a round in `ta`; when a
-             * set has been tested, the piece after the one in the other set is loaded into it */
-            while (true) {
-                leaf_piece_test<MODE>(now, ta, L, lane);
-                leaf_piece_next(ahead, L.cur);
-                leaf_piece_load(ahead, sc.soa, lane, ta);
-                leaf_piece_next(now, L.cur);
-                if (!now.valid) break;
-                leaf_piece_test<MODE>(now, tb, L, lane);
-                leaf_piece_next(ahead, L.cur);
-                leaf_piece_load(ahead, sc.soa, lane, tb);
-                leaf_piece_next(now, L.cur);
-                if (!now.valid) break;
-            }
-        }
-
-        /* ---- start the refilled lanes ---- */
-        bool defer = false;
-        if (starting) {
-            if (MODE == TRACE_SHADOW_ANY && !(dist >= 1.0f)) defer = true;
-            else {
-                ray_set_recip(L.r);
-                lane_start(L, sc.leafwise_root, sc.root, scene_tame);
-                if (MODE == TRACE_SHADOW_BOUNDED) L.best.t = dist;
-                ray = (int32_t)new_ray;
-            }
-        }
-        if (MODE == TRACE_SHADOW_ANY) {
-            const uint64_t dm = __ballot(defer);
-            if (dm) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.defer_count, (uint32_t)__popcll(dm));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (defer) a.defer_list[base + (uint32_t)__popcll(dm & lt_mask)] = new_ray;
-            }
-        }
-        const bool active = ray >= 0;
-
-        /* ---- one interior node per lane that has its record ---- */
-        {
-            NodeData nd;
-            nd.lo[0] = pt_f2{q0.x, q0.y}; nd.lo[1] = pt_f2{q0.z, q0.w}; nd.lo[2] = pt_f2{q1.x, q1.y};
-            nd.hi[0] = pt_f2{q1.z, q1.w}; nd.hi[1] = pt_f2{q2.x, q2.y}; nd.hi[2] = pt_f2{q2.z, q2.w};
-            nd.lo_ref = __float_as_uint(q3.x); nd.hi_ref = __float_as_uint(q3.y); nd.axis = __float_as_uint(q3.z);
-            if (__any(rec_node && !L.tame)) {
-                if (rec_node) lane_node<true, false>(L, nd, st);
-            } else {
-                if (rec_node) lane_node<true, true>(L, nd, st);
-            }
-        }
-        if (active && L.cur == PT_REF_NONE && L.sp > 0) lane_pop<true>(L, st);
-
-        /* ---- next round's node records, and the first two pieces of the leaves now pending ---- */
-        rec_node = active && lane_has_node(L);
-        if (rec_node) {
-            const float4* rec = (const float4*)(sc.leafwise_nodes + L.cur * (uint32_t)sizeof(pt_flat_node));
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-        }
-        pending = __ballot(active && lane_has_leaf(L));
-        ahead.rest = pending; ahead.valid = 0u;
-        leaf_piece_next(ahead, L.cur);
-        leaf_piece_load(ahead, sc.soa, lane, ta);
-        leaf_piece_next(ahead, L.cur);
-        leaf_piece_load(ahead, sc.soa, lane, tb);
-
-        /* ---- retire finished rays ---- */
-        if (active && lane_finished(L)) {
-            a.vis[a.target ? tgt : (uint32_t)ray] = L.found ? 0 : 1;
-            ray = -1;
-        }
-
-        /* ---- refill idle lanes (as k_trace) ---- */
-        const uint64_t idle = __ballot(ray < 0);
-        starting = false;
-        if (idle) {
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (!exhausted && (n_idle >= REFILL_MIN_ANY || idle == ~0ull)) {
-                if (pool_next >= pool_end) {
-                    uint32_t c = total_chunks;
-                    if (first_chunk) {
-                        c = ((xcd_wave / TRACE_XCD_SUPER) * 8u + xcd) * TRACE_XCD_SUPER + xcd_wave % TRACE_XCD_SUPER;
-                    } else if (!static_only) {
-                        while (tried < 8u) {
-                            uint32_t k = 0;
-                            if (lane == 0) k = atomicAdd(a.d_next_chunk + from_xcd * 8u, 1u);
-                            k = xcd_waves + __builtin_amdgcn_readfirstlane(k);
-                            c = ((k / TRACE_XCD_SUPER) * 8u + from_xcd) * TRACE_XCD_SUPER + k % TRACE_XCD_SUPER;
-                            if (c < total_chunks) break;
-                            from_xcd = (from_xcd + 1u) & 7u; tried++;
-                            c = total_chunks;
-                        }
-                    }
-                    first_chunk = false;
-                    if (c < total_chunks) {
-                        const uint64_t first = (uint64_t)c * chunk;
-                        pool_next = (uint32_t)first;
-                        pool_end = (uint32_t)min((uint64_t)n, first + chunk);
-                    } else {
-                        exhausted = true;
-                    }
-                }
-                if (!exhausted) {
-                    uint32_t k = pool_next + (uint32_t)__popcll(idle & lt_mask);
-                    starting = (ray < 0) && (k < pool_end);
-                    new_ray = k;
-                    pool_next = min(pool_end, pool_next + n_idle);
-                }
-            }
-            if (exhausted && idle == ~0ull) break;
-        }
-        if (starting) {
-            dist = a.dist[new_ray]; if (a.target) tgt = a.target[new_ray];
-            L.r.ox = a.rays.ox[new_ray]; L.r.oy = a.rays.oy[new_ray]; L.r.oz = a.rays.oz[new_ray];
-            L.r.dx = a.rays.dx[new_ray]; L.r.dy = a.rays.dy[new_ray]; L.r.dz = a.rays.dz[new_ray];
-        }
-    }
-}
-
 /* ------------------------------------------------------- wavefront renderer */
 
 struct DLight { V3f pos, color; };
@@ -1787,7 +1612,6 @@ struct pt_scene {
     void* d_shade = nullptr;
     void* d_leafwise = nullptr;   /* k_shadow_leafwise: rewritten node records, then the triangles by component */
     bool use_leafwise = false;
-    int leafwise_mode = 0;        /* PT_LEAFWISE: 1 any-hit walks (k_shadow_leafwise), 2 every walk (k_trace<MODE, 0>), 3 both */
     uint32_t* d_piece_start = nullptr;   /* inside d_leafwise */
     int grid_leafwise = 0, grid_leafwise_closest = 0;
     uint64_t n_tris = 0;
@@ -1962,9 +1786,11 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
      * launches 26 % slower); where it streams from HBM they win (21.5 M triangles: shadow launches
      * 4 % faster).  So: only for geometry larger than the 256 MiB Infinity Cache.  PT_QNODES=0 / 1
      * overrides. */
+    bool want_leafwise = n_leaves > 0 && flat->n_tris >= (uint64_t)LEAFWISE_MIN_AVERAGE_LEAF * n_leaves && largest_leaf <= LEAFWISE_MAX_COUNT;
+    if (const char* e = getenv("PT_LEAFWISE")) want_leafwise = atoi(e) >= 1;
     ptq::QNodes qn;
     {
-        bool want = tris_off + tb > ((size_t)256 << 20);
+        bool want = tris_off + tb > ((size_t)256 << 20) && !want_leafwise;   /* the leafwise walks read exact records */
         if (const char* e = getenv("PT_QNODES")) want = atoi(e) == 1;
         if (want) ptq::build_qnodes(flat, qn);
     }
@@ -1992,11 +1818,11 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
      * 16 % slower than k_trace<SHADOW_ANY>). */
     s->use_dense = false;
     if (const char* e = getenv("PT_DENSE_SHADOW")) s->use_dense = atoi(e) == 1 && !with_q && largest_leaf > 0 && largest_leaf <= PT_REF_COUNT_MASK;
-    /* Wave-wide leaf tests for the light-visibility walk (k_shadow_leafwise), PT_LEAFWISE=1: every leaf
-     * at most 255 triangles. */
+    /* Wave-wide leaf tests (k_trace<MODE, 0>): for scenes whose leaves are large; every leaf at most
+     * 255 triangles.  PT_LEAFWISE = 0 / 1 overrides. */
     s->use_leafwise = false;
-    if (const char* e = getenv("PT_LEAFWISE")) {
-        if (atoi(e) >= 1 && atoi(e) <= 3 && flat->n_tris > 0) {
+    {
+        if (want_leafwise && flat->n_tris > 0) {
             LeafwiseBuild lw;
             leafwise_build(flat, lw);
             if (lw.ok) {
@@ -2024,7 +1850,6 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
                 if (d_tab) (void)hipFree(d_tab);
                 if (!good) return cleanup(fail(PT_ERR_DEVICE, "setting up the component-wise leaves failed"));
                 s->use_leafwise = true;
-                s->leafwise_mode = atoi(e);
                 s->d_piece_start = (uint32_t*)((char*)s->d_leafwise + nodes_b + soa_b);
                 s->d.leafwise_nodes = (const char*)s->d_leafwise;
                 s->d.soa = (const float*)((const char*)s->d_leafwise + nodes_b);
@@ -2120,11 +1945,7 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     ScopedTimer tm(s, (MODE == TRACE_CLOSEST_MESH || MODE == TRACE_CLOSEST_FLAT) ? PT_KERNEL_CLOSEST : MODE == TRACE_SHADOW_EXACT ? PT_KERNEL_SHADOW_EXACT : PT_KERNEL_SHADOW, here.stream);
     constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
     const dim3 grid(trace_grid(s, ANY));
-    if (ANY && s->use_leafwise && s->leafwise_mode != 2) {
-        constexpr int LMODE = ANY ? MODE : TRACE_SHADOW_ANY;   /* (keeps the closest-hit instantiations of this function valid) */
-        hipLaunchKernelGGL(k_shadow_leafwise<LMODE>, dim3(s->grid_leafwise), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
-    }
-    else if (s->use_leafwise && s->leafwise_mode >= 2) {
+    if (s->use_leafwise) {
         hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(ANY ? s->grid_leafwise : s->grid_leafwise_closest), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
         if (MODE == TRACE_CLOSEST_FLAT || MODE == TRACE_CLOSEST_MESH) {
             HIP_TRY(hipGetLastError());
@@ -2175,7 +1996,7 @@ static int init_trace_launch(pt_scene* s) {
     per_cu_d = std::max(1, std::min(per_cu_d, 8));
     s->grid_dense = std::max(8, (s->num_cus * per_cu_d) & ~7);
     int per_cu_l = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_shadow_leafwise<TRACE_SHADOW_ANY>, TRACE_BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_trace<TRACE_SHADOW_ANY, 0>, TRACE_BLOCK, 0));
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_l = v; }
     per_cu_l = std::max(1, std::min(per_cu_l, 8));
     s->grid_leafwise = std::max(8, (s->num_cus * per_cu_l) & ~7);
@@ -2213,6 +2034,15 @@ static int fill_miss_closest(pt_scene* s, uint64_t n, int32_t* d_idx, float* d_t
 }
 
 extern "C" {
+
+int pt_scene_trace_variant(const pt_scene* s, int32_t out[4]) {
+    if (!s || !out) return fail(PT_ERR_INVALID, "null argument");
+    out[0] = s->use_leafwise ? 0 : s->tris_per_round;
+    out[1] = s->use_qnodes && !s->use_leafwise ? 1 : 0;
+    out[2] = s->use_dense && !s->use_leafwise ? 1 : 0;
+    out[3] = 0;
+    return PT_OK;
+}
 
 int pt_raycast_closest_dev(pt_scene* s, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                            const float* dy, const float* dz, int32_t* idx, float* t, float* u, float* v) {

@@ -101,7 +101,7 @@ def host_lib():
 HIP_SYMBOLS = [
     "pt_device_count", "pt_device_prepare", "pt_scene_create", "pt_scene_destroy", "pt_raycast_closest", "pt_raycast_closest_dev",
     "pt_raycast_closest_dev_noalloc",
-    "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_raycast_occluded", "pt_raycast_occluded_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_film_create",
+    "pt_raycast_shadow", "pt_raycast_shadow_dev", "pt_raycast_occluded", "pt_raycast_occluded_dev", "pt_scene_sync", "pt_scene_kernel_time", "pt_scene_trace_variant", "pt_film_create",
     "pt_film_destroy", "pt_film_zero", "pt_film_device_ptr", "pt_film_read", "pt_film_add", "pt_films_reduce", "pt_render_passes",
     "pt_camera_rays_dev", "pt_cast_rays", "pt_last_error", "pt_build_info",
 ]
@@ -138,6 +138,7 @@ def hip_lib():
         L.pt_raycast_occluded_dev.argtypes = [vp, u64] + [vp] * 8
         L.pt_scene_sync.argtypes = [vp]
         L.pt_scene_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+        L.pt_scene_trace_variant.argtypes = [vp, vp]
         L.pt_film_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
         L.pt_film_destroy.argtypes = [vp]
         L.pt_film_destroy.restype = None

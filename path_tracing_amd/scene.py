@@ -172,6 +172,12 @@ class GpuScene:
               "pt_scene_kernel_time")
         return ms.value, n.value
 
+    def trace_variant(self):
+        """Which trace kernels this scene's geometry selected (pt_scene_trace_variant)."""
+        out = np.zeros(4, dtype=np.int32)
+        check(native.hip_lib().pt_scene_trace_variant(self.h, _p(out)), "pt_scene_trace_variant")
+        return dict(tris_per_round=int(out[0]), leafwise=int(out[0]) == 0, qnodes=bool(out[1]), dense=bool(out[2]))
+
     # -- host-pointer entry points (numpy in, numpy out) ---------------------------------
     def raycast_closest(self, origins, dirs):
         o = _f32(origins).reshape(-1, 3)

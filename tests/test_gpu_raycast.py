@@ -405,42 +405,35 @@ def test_deferred_dense_triangle_tests(scene_small, scene_medium, monkeypatch):
 
 
 def test_wave_wide_leaf_tests(scene_small, scene_medium, monkeypatch):
-    """PT_LEAFWISE=1 answers the light-visibility tests with k_shadow_leafwise: a lane that reaches a
-    leaf leaves it to the wave, which tests it one triangle per lane from a component-by-component
-    copy of the triangles.  Same visibility bit for bit on every ray set, in both shadow modes, on
+    """PT_LEAFWISE=1 traces with k_trace<MODE, 0>: a lane that reaches a leaf leaves it to the wave,
+    which tests it one triangle per lane from a component-by-component copy of the triangles.  Same
+    closest hits and the same visibility, bit for bit, on every ray set, in both shadow modes, on
     ordinary leaves and on leaves of up to 200 triangles (more than one 64-triangle piece), and the
     same film."""
     rng = np.random.default_rng(41)
     # 200 copies of a few triangles make leaves that the "no improvement" rule cannot split
-    few = scene_small.tris[:: max(1, len(scene_small.tris) // 40)][:40]
-    stacked = np.ascontiguousarray(np.concatenate([np.repeat(few[:3], 200 // 3, axis=0), scene_small.tris]))
+    stacked = np.ascontiguousarray(np.concatenate([np.repeat(scene_small.tris[:3], 200 // 3, axis=0), scene_small.tris]))
     stacked_host = pta.HostScene(stacked)
     assert stacked_host.tree_stats()["largest_leaf"] > 64
     stacked_oracle = orc.Scene(stacked)
     monkeypatch.setenv("PT_LEAFWISE", "1")
-    wide = {id(sc): pta.GpuScene(sc.host, 0) for sc in (scene_small, scene_medium)}
-    stacked_gpu = pta.GpuScene(stacked_host, 0)
-    # =2: every walk, the closest-hit ones included
-    monkeypatch.setenv("PT_LEAFWISE", "2")
-    all_walks = [(pta.GpuScene(sc.host, 0), sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(pta.GpuScene(stacked_host, 0), stacked_oracle, stacked)]
+    cases = [(pta.GpuScene(sc.host, 0), sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(pta.GpuScene(stacked_host, 0), stacked_oracle, stacked)]
     monkeypatch.delenv("PT_LEAFWISE")
-    cases = [(wide[id(sc)], sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(stacked_gpu, stacked_oracle, stacked)] + all_walks
     for g, oracle, tris in cases:
         for name, (o, d) in all_ray_sets(tris, 20000).items():
-            if any(g is w[0] for w in all_walks):
-                assert_hits_equal(g.raycast_closest(o, d), oracle.raycast(o, d), name + " closest")
+            want = oracle.raycast(o, d)
+            assert_hits_equal(g.raycast_closest(o, d), want, name + " closest")
             dist = np.where(rng.random(len(o)) < 0.3, rng.random(len(o)), 1.0 + 4.0 * rng.random(len(o))).astype(np.float32)
             assert np.array_equal(g.raycast_shadow(o, d, dist), oracle.shadow_visible(o, d, dist)), name
-            idx, t, _, _ = oracle.raycast(o, d)
+            idx, t = want[0], want[1]
             bound = np.where(idx >= 0, t * np.float32(1.5), np.float32(1.0)).astype(np.float32)
             bound[::3] = t[::3] * np.float32(0.5)
             assert np.array_equal(g.raycast_shadow(o, d, bound, bounded=True), oracle.shadow_visible(o, d, bound, bounded=True)), name + " bounded"
     cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5)
     films = []
-    for g in (scene_medium.gpu, wide[id(scene_medium)], all_walks[1][0]):
+    for g in (scene_medium.gpu, cases[1][0]):
         f = pta.Film(g, 320, 200)
         st = f.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, 4)], seed=31)
         films.append((f.read(), (st.closest_rays, st.shadow_rays, st.shadow_rays_traced)))
-    for other in films[1:]:
-        assert films[0][1] == other[1]
-        assert np.array_equal(films[0][0][0].view(np.uint32), other[0][0].view(np.uint32)) and np.array_equal(films[0][0][1], other[0][1])
+    assert films[0][1] == films[1][1]
+    assert np.array_equal(films[0][0][0].view(np.uint32), films[1][0][0].view(np.uint32)) and np.array_equal(films[0][0][1], films[1][0][1])

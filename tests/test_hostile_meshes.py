@@ -90,7 +90,7 @@ def test_host_tree_and_lane_walk(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MESH_NAMES)
-@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW", "PT_LEAFWISE", "PT_LEAFWISE=2"])
+@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW", "PT_LEAFWISE"])
 def test_gpu_matches_oracle(name, option, monkeypatch):
     """option: the any-hit walks on quantised interior nodes, with deferred dense triangle tests, or
     with leaves tested by the whole wave (=2: the closest-hit walks too)."""
