@@ -67,6 +67,7 @@ struct DScene {
     RootBox root;
     /* quantised interior nodes of the any-hit walks (traverse_core.h "q-nodes"), in the same allocation */
     uint32_t q_off;       /* byte offset of the 32-byte q-node records */
+    uint32_t leafwise_q_off; /* ... of the copy that sits behind the leafwise walks' node records (their base is leafwise_nodes) */
     uint32_t q_root;      /* the root's position for walks on q-nodes; PT_REF_NONE: the scene has none */
     uint32_t q_root_exact; /* ... for rays that must stay on exact records (not tame) */
     QGrid grid;
@@ -99,9 +100,18 @@ struct RaySoAW {
 #ifndef TRACE_XCD_SUPER
 #define TRACE_XCD_SUPER 64u /* chunks per super-chunk: consecutive super-chunks go to the 8 XCDs in turn (0: one shared queue) */
 #endif
+#ifndef TRACE_SETPRIO
+#define TRACE_SETPRIO 0    /* 1: a wave runs its pops and issues its record loads at raised priority; 2: everything from the round's wait to there */
+#endif
+#ifndef TRACE_EARLY_PEEK
+#define TRACE_EARLY_PEEK 0 /* 1: the stack entries a round's pops consume are read at the top of the round */
+#endif
 #ifndef TRACE_MAX_POPS
 #define TRACE_MAX_POPS 1   /* stack pops a lane may take in one round before it has to wait for the next
                               (1 / 2 / 3 on the full render: 6 360 / 6 280 / 6 170 Mrays/s) */
+#endif
+#if TRACE_EARLY_PEEK && TRACE_MAX_POPS > 1
+#error "the early stack reads serve one pop per round"
 #endif
 #ifndef SHADE_GRID_MUL
 #define SHADE_GRID_MUL 8   /* workgroups per CU of the shade kernel's grid (2 / 4 / 8 / 16: 33.7 / 33.2 / 30.6 / 29.6 ms) */
@@ -168,6 +178,17 @@ struct LaneStack {
             push(sp, b);
             push(sp, c);
         }
+    }
+    /* the LDS part alone: what peek1 / peek3 return while sp <= STACK_LDS */
+    __device__ __forceinline__ uint32_t lds_peek1(int sp) const {
+        const int s = sp < STACK_LDS ? sp : STACK_LDS;
+        return lds[(s - 1) * TRACE_BLOCK];
+    }
+    __device__ __forceinline__ void lds_peek3(int sp, uint32_t& e, uint32_t& w1, uint32_t& w2) const {
+        const int s = sp < STACK_LDS ? sp : STACK_LDS;
+        e = lds[(s - 1) * TRACE_BLOCK];
+        w1 = lds[(s - 2) * TRACE_BLOCK];
+        w2 = lds[(s - 3) * TRACE_BLOCK];
     }
     __device__ __forceinline__ uint32_t peek1(int sp) const {
         const int s = sp < STACK_LDS ? sp : STACK_LDS;
@@ -249,6 +270,9 @@ struct TraceArgs {
 #define LEAFWISE_PIECE_WORDS (9u * LEAFWISE_PIECE)
 #define LEAFWISE_MAX_COUNT 255u
 #define LEAFWISE_MAX_PIECES (1u << 22)
+#ifndef LEAFWISE_QNODES_BY_DEFAULT
+#define LEAFWISE_QNODES_BY_DEFAULT 0               /* 1: the leafwise any-hit walks of scenes beyond the Infinity Cache read quantised interior nodes */
+#endif
 #ifndef LEAFWISE_MIN_AVERAGE_LEAF
 #define LEAFWISE_MIN_AVERAGE_LEAF 32u              /* triangles per leaf, on average, from which a scene gets these kernels
                                                       (measured on MI355X: 41 per leaf +23 %, 10 per leaf -34 %, 5.6 per leaf -54 %) */
@@ -381,7 +405,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
     /* TPR = 0: a lane does not walk its leaf; the wave tests it in the next round ("WAVE-WIDE leaf
      * tests" above).  Hits are then named by piece and slot, k_leafwise_positions translates. */
     constexpr bool COOP = TPR == 0;
-    static_assert(!(COOP && QN), "the leafwise walk reads exact node records");
     /* QN: interior nodes whose children are both interior are read as 32-byte quantised records (two
      * load pieces instead of four); any-hit walks only, whose answer does not depend on which
      * enclosing boxes the interior levels are tested against (traverse_core.h "q-nodes") */
@@ -498,6 +521,22 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             }
         }
 
+#if TRACE_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(2);
+#endif
+#if TRACE_EARLY_PEEK
+        /* The stack entries this round's pops will consume are asked for NOW, while the sections below
+         * run: a lane that pops at the end of this round has not pushed in it (a push leaves the lane
+         * with a child to enter; a lane that starts a ray begins with an empty stack), so the top of its
+         * stack is already what the pop will find, and the LDS round trip is off the round's critical
+         * path (the next records' addresses wait on the pops). */
+        uint32_t pk_e = 0u, pk_w1 = 0u, pk_w2 = 0u;
+        if (ray >= 0 && L.sp > 0) {
+            if (ANY) pk_e = st.lds_peek1(L.sp);
+            else st.lds_peek3(L.sp, pk_e, pk_w1, pk_w2);
+        }
+#endif
+
         /* ---- start the refilled lanes (they take their first record with everyone else below) ---- */
         bool defer = false;
         if (starting) {
@@ -509,7 +548,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
                 ray_set_recip(L.r);
                 /* with q-nodes every node position is in their numbering; rays that are not tame start
                  * on the exact root and stay on exact records */
-                const uint32_t root_pos = COOP ? sc.leafwise_root : QN ? ((scene_tame && ray_is_tame(L.r)) ? sc.q_root : sc.q_root_exact) : sc.root_ref;
+                /* (a scene has q-nodes only if its root is interior, and interior positions are the same
+                 * in the leafwise copy of the node array) */
+                const uint32_t root_pos = QN ? ((scene_tame && ray_is_tame(L.r)) ? sc.q_root : sc.q_root_exact) : COOP ? sc.leafwise_root : sc.root_ref;
                 lane_start(L, root_pos, sc.root, scene_tame);
                 /* a triangle counts only if it is strictly nearer than the best so far: starting
                  * from the bound instead of infinity makes that "nearer than the light" */
@@ -579,9 +620,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             }
         }
 
+#if TRACE_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(2);
+#endif
         /* ---- lanes left with neither a leaf nor a node take their next one from the stack ---- */
         if (active && L.cur == PT_REF_NONE && L.sp > 0) {
+#if TRACE_EARLY_PEEK
+            if (__builtin_expect(L.sp > STACK_LDS, 0)) {   /* the top is in the spill area */
+                if (ANY) pk_e = st.peek1(L.sp); else st.peek3(L.sp, pk_e, pk_w1, pk_w2);
+            }
+            lane_pop_entries<ANY>(L, pk_e, pk_w1, pk_w2);
+#else
             lane_pop<ANY>(L, st);
+#endif
 #if TRACE_MAX_POPS >= 2
             if (L.cur == PT_REF_NONE && L.sp > 0) lane_pop<ANY>(L, st);
 #endif
@@ -598,7 +649,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             const bool rec_exact = !QN || L.cur >= PT_Q_EXACT_BASE;   /* (for a node) an exact 64-byte record */
             const uint32_t off = rec_tri ? sc.tris_off + lane_leaf_pos(L) * (uint32_t)sizeof(pt_tri_isect)
                                : !QN ? L.cur * (uint32_t)sizeof(pt_flat_node)
-                               : rec_exact ? (L.cur - PT_Q_EXACT_BASE) * (uint32_t)sizeof(pt_flat_node) : sc.q_off + L.cur * 32u;
+                               : rec_exact ? (L.cur - PT_Q_EXACT_BASE) * (uint32_t)sizeof(pt_flat_node) : (COOP ? sc.leafwise_q_off : sc.q_off) + L.cur * 32u;
             const float4* rec = (const float4*)((COOP ? sc.leafwise_nodes : sc.geom) + off);
             q0 = rec[0]; q1 = rec[1];
             if (!QN || rec_tri || rec_exact) q2 = rec[2];
@@ -612,6 +663,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TPR
             }
         }
 
+#if TRACE_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (COOP) {   /* the first two pieces of the leaves now pending */
             pending = __ballot(active && lane_has_leaf(L));
             ahead.rest = pending; ahead.valid = 0u;
@@ -759,6 +813,17 @@ struct AnyStack {
         sp++;
     }
     __device__ __forceinline__ void push_frame(int&, bool, uint32_t, uint32_t, uint32_t) {}   /* closest-hit only */
+    /* the LDS part alone: what peek1 / peek3 return while sp <= STACK_LDS */
+    __device__ __forceinline__ uint32_t lds_peek1(int sp) const {
+        const int s = sp < STACK_LDS ? sp : STACK_LDS;
+        return lds[(s - 1) * TRACE_BLOCK];
+    }
+    __device__ __forceinline__ void lds_peek3(int sp, uint32_t& e, uint32_t& w1, uint32_t& w2) const {
+        const int s = sp < STACK_LDS ? sp : STACK_LDS;
+        e = lds[(s - 1) * TRACE_BLOCK];
+        w1 = lds[(s - 2) * TRACE_BLOCK];
+        w2 = lds[(s - 3) * TRACE_BLOCK];
+    }
     __device__ __forceinline__ uint32_t peek1(int sp) const {
         const int s = sp < DENSE_STACK_LDS ? sp : DENSE_STACK_LDS;
         uint32_t e = lds[(s - 1) * TRACE_BLOCK];
@@ -1638,6 +1703,7 @@ struct pt_scene {
     int grid_closest = 0, grid_any = 0, grid_dense = 0; /* resident blocks of the persistent trace kernels */
     int tris_per_round = 1;             /* 2, 3: the trace kernels that test that many triangles of a leaf per round (large leaves) */
     bool use_qnodes = false;            /* the any-hit launches use the kernels that read quantised interior nodes */
+    bool use_qnodes_leafwise = false;   /* ... in their leafwise form (use_leafwise) */
     bool use_dense = false;             /* the reference's light test is answered by k_shadow_dense (deferred, dense triangle tests) */
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
@@ -1790,14 +1856,15 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
     if (const char* e = getenv("PT_LEAFWISE")) want_leafwise = atoi(e) >= 1;
     ptq::QNodes qn;
     {
-        bool want = tris_off + tb > ((size_t)256 << 20) && !want_leafwise;   /* the leafwise walks read exact records */
+        bool want = tris_off + tb > ((size_t)256 << 20) && (!want_leafwise || LEAFWISE_QNODES_BY_DEFAULT);
         if (const char* e = getenv("PT_QNODES")) want = atoi(e) == 1;
         if (want) ptq::build_qnodes(flat, qn);
     }
     const size_t q_off = (tris_off + tb + 255) & ~(size_t)255;
     const size_t qb = qn.rec.size() * sizeof(ptq::QNodeRec);
     if (q_off + qb >= ((size_t)1 << 32)) qn.rec.clear();
-    const bool with_q = !qn.rec.empty();
+    /* the leafwise any-hit walks read their q-nodes from a copy behind their own node records */
+    const bool with_q = !qn.rec.empty() && !want_leafwise;
     if (hipMalloc(&s->d_geom, with_q ? q_off + qb : tris_off + tb) != hipSuccess ||
         hipMalloc(&s->d_shade, sb) != hipSuccess || hipMalloc((void**)&s->d_small, SMALL_WORDS * sizeof(uint32_t)) != hipSuccess)
         return cleanup(fail(PT_ERR_DEVICE, "hipMalloc failed for the scene arrays"));
@@ -1829,10 +1896,13 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
                 const size_t nodes_b = (std::max<size_t>(flat->n_nodes, 1) * sizeof(pt_flat_node) + 255) & ~(size_t)255;
                 const size_t soa_b = std::max<uint64_t>(lw.pieces, 1) * LEAFWISE_PIECE_WORDS * sizeof(float);
                 const size_t nl = lw.start.size();
-                const size_t ps_b = std::max<size_t>(lw.piece_start.size(), 1) * sizeof(uint32_t);
+                const size_t ps_b = (std::max<size_t>(lw.piece_start.size(), 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
+                const size_t lq_off = nodes_b + soa_b + ps_b;
+                const bool lw_q = !qn.rec.empty() && lq_off + qb < ((size_t)1 << 32);
                 uint32_t* d_tab = nullptr;
-                bool good = hipMalloc(&s->d_leafwise, nodes_b + soa_b + ps_b) == hipSuccess && hipMalloc((void**)&d_tab, std::max<size_t>(nl, 1) * 12) == hipSuccess;
+                bool good = hipMalloc(&s->d_leafwise, lq_off + (lw_q ? qb : 0)) == hipSuccess && hipMalloc((void**)&d_tab, std::max<size_t>(nl, 1) * 12) == hipSuccess;
                 good = good && hipMemset((char*)s->d_leafwise + nodes_b, 0, soa_b) == hipSuccess;
+                if (good && lw_q) good = hipMemcpy((char*)s->d_leafwise + lq_off, qn.rec.data(), qb, hipMemcpyHostToDevice) == hipSuccess;
                 if (good && !lw.piece_start.empty())
                     good = hipMemcpy((char*)s->d_leafwise + nodes_b + soa_b, lw.piece_start.data(), lw.piece_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
                 if (good && flat->n_nodes) good = hipMemcpy(s->d_leafwise, lw.nodes.data(), flat->n_nodes * sizeof(pt_flat_node), hipMemcpyHostToDevice) == hipSuccess;
@@ -1850,6 +1920,8 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
                 if (d_tab) (void)hipFree(d_tab);
                 if (!good) return cleanup(fail(PT_ERR_DEVICE, "setting up the component-wise leaves failed"));
                 s->use_leafwise = true;
+                s->use_qnodes_leafwise = lw_q;
+                s->d.leafwise_q_off = (uint32_t)lq_off;
                 s->d_piece_start = (uint32_t*)((char*)s->d_leafwise + nodes_b + soa_b);
                 s->d.leafwise_nodes = (const char*)s->d_leafwise;
                 s->d.soa = (const float*)((const char*)s->d_leafwise + nodes_b);
@@ -1858,7 +1930,7 @@ int pt_scene_create(int device, const pt_flat_scene* flat, pt_scene** out) {
         }
     }
     s->d.q_off = (uint32_t)q_off;
-    s->d.q_root = with_q ? qn.root : PT_REF_NONE;
+    s->d.q_root = (with_q || s->use_qnodes_leafwise) ? qn.root : PT_REF_NONE;
     s->d.q_root_exact = PT_Q_EXACT_BASE + flat->root_ref;
     s->d.grid = qn.grid;
     s->d.geom = (const char*)s->d_geom;
@@ -1946,7 +2018,9 @@ static int launch_trace(pt_scene* s, TraceArgs a, const LaunchCtx* ctx = nullptr
     constexpr bool ANY = MODE == TRACE_SHADOW_ANY || MODE == TRACE_SHADOW_BOUNDED;
     const dim3 grid(trace_grid(s, ANY));
     if (s->use_leafwise) {
-        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(ANY ? s->grid_leafwise : s->grid_leafwise_closest), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+        constexpr int QMODE = ANY ? MODE : TRACE_SHADOW_ANY;   /* (keeps the closest-hit instantiations of this function valid) */
+        if (ANY && s->use_qnodes_leafwise) hipLaunchKernelGGL((k_trace<QMODE, 0, true>), dim3(s->grid_leafwise), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
+        else hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(ANY ? s->grid_leafwise : s->grid_leafwise_closest), dim3(TRACE_BLOCK), 0, here.stream, s->d, a);
         if (MODE == TRACE_CLOSEST_FLAT || MODE == TRACE_CLOSEST_MESH) {
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_leafwise_positions, dim3((unsigned)std::max(8, s->num_cus * 8)), dim3(256), 0, here.stream, a.d_count, a.count_mul,
@@ -1996,7 +2070,8 @@ static int init_trace_launch(pt_scene* s) {
     per_cu_d = std::max(1, std::min(per_cu_d, 8));
     s->grid_dense = std::max(8, (s->num_cus * per_cu_d) & ~7);
     int per_cu_l = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_trace<TRACE_SHADOW_ANY, 0>, TRACE_BLOCK, 0));
+    if (s->use_qnodes_leafwise) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_trace<TRACE_SHADOW_ANY, 0, true>, TRACE_BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_trace<TRACE_SHADOW_ANY, 0>, TRACE_BLOCK, 0));
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_l = v; }
     per_cu_l = std::max(1, std::min(per_cu_l, 8));
     s->grid_leafwise = std::max(8, (s->num_cus * per_cu_l) & ~7);
@@ -2038,7 +2113,7 @@ extern "C" {
 int pt_scene_trace_variant(const pt_scene* s, int32_t out[4]) {
     if (!s || !out) return fail(PT_ERR_INVALID, "null argument");
     out[0] = s->use_leafwise ? 0 : s->tris_per_round;
-    out[1] = s->use_qnodes && !s->use_leafwise ? 1 : 0;
+    out[1] = (s->use_leafwise ? s->use_qnodes_leafwise : s->use_qnodes) ? 1 : 0;
     out[2] = s->use_dense && !s->use_leafwise ? 1 : 0;
     out[3] = 0;
     return PT_OK;

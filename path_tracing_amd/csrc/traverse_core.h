@@ -245,18 +245,15 @@ PT_HD void lane_start(Lane& L, uint32_t root_ref, const RootBox& root, bool scen
     lane_enter(L, box_hit(rb, L.r) ? root_ref : PT_REF_NONE);
 }
 
-template <bool ANYHIT, class Stack>
-PT_HD void lane_pop(Lane& L, Stack& st) {
-    /* The top three entries are read together (a frame is at most three dwords) so that the
-     * reads do not wait on one another; how many are consumed is decided afterwards. */
-    uint32_t e, w1, w2;
+/* One pop, given the top entries of the lane's stack: e = entry sp-1, w1 = entry sp-2, w2 = entry
+ * sp-3 (w1 and w2 are used only by the closest-hit walk, and only where a frame has them). */
+template <bool ANYHIT>
+PT_HD void lane_pop_entries(Lane& L, uint32_t e, uint32_t w1, uint32_t w2) {
     if (ANYHIT) {
-        e = st.peek1(L.sp);
         L.sp -= 1;
         lane_enter(L, e);
         return;
     }
-    st.peek3(L.sp, e, w1, w2);
     const float inf = pt_inf();
     const bool frame = (e & PT_REF_FRAME) != 0;
     const bool kept = frame && (L.frame_bits & 1u) != 0;
@@ -270,6 +267,16 @@ PT_HD void lane_pop(Lane& L, Stack& st) {
     L.frame_bits = frame ? (L.frame_bits >> 1) : L.frame_bits;
     L.local = frame ? merged : near_local;
     lane_enter(L, (frame && !visit) ? PT_REF_NONE : (e & ~PT_REF_FRAME));
+}
+
+template <bool ANYHIT, class Stack>
+PT_HD void lane_pop(Lane& L, Stack& st) {
+    /* The top three entries are read together (a frame is at most three dwords) so that the
+     * reads do not wait on one another; how many are consumed is decided afterwards. */
+    uint32_t e, w1 = 0u, w2 = 0u;
+    if (ANYHIT) e = st.peek1(L.sp);
+    else st.peek3(L.sp, e, w1, w2);
+    lane_pop_entries<ANYHIT>(L, e, w1, w2);
 }
 
 /* TAME selects the cheaper box test; it may be used only for lanes with L.tame set. */

@@ -404,12 +404,13 @@ def test_deferred_dense_triangle_tests(scene_small, scene_medium, monkeypatch):
     assert np.array_equal(films[0][0][0].view(np.uint32), films[1][0][0].view(np.uint32)) and np.array_equal(films[0][0][1], films[1][0][1])
 
 
-def test_wave_wide_leaf_tests(scene_small, scene_medium, monkeypatch):
+@pytest.mark.parametrize("qnodes", [False, True])
+def test_wave_wide_leaf_tests(scene_small, scene_medium, monkeypatch, qnodes):
     """PT_LEAFWISE=1 traces with k_trace<MODE, 0>: a lane that reaches a leaf leaves it to the wave,
     which tests it one triangle per lane from a component-by-component copy of the triangles.  Same
     closest hits and the same visibility, bit for bit, on every ray set, in both shadow modes, on
     ordinary leaves and on leaves of up to 200 triangles (more than one 64-triangle piece), and the
-    same film."""
+    same film.  qnodes: the any-hit walks of these kernels on quantised interior nodes (PT_QNODES=1)."""
     rng = np.random.default_rng(41)
     # 200 copies of a few triangles make leaves that the "no improvement" rule cannot split
     stacked = np.ascontiguousarray(np.concatenate([np.repeat(scene_small.tris[:3], 200 // 3, axis=0), scene_small.tris]))
@@ -417,8 +418,12 @@ def test_wave_wide_leaf_tests(scene_small, scene_medium, monkeypatch):
     assert stacked_host.tree_stats()["largest_leaf"] > 64
     stacked_oracle = orc.Scene(stacked)
     monkeypatch.setenv("PT_LEAFWISE", "1")
+    if qnodes:
+        monkeypatch.setenv("PT_QNODES", "1")
     cases = [(pta.GpuScene(sc.host, 0), sc.oracle, sc.tris) for sc in (scene_small, scene_medium)] + [(pta.GpuScene(stacked_host, 0), stacked_oracle, stacked)]
     monkeypatch.delenv("PT_LEAFWISE")
+    monkeypatch.delenv("PT_QNODES", raising=False)
+    assert all(g.trace_variant()["qnodes"] == qnodes for g, _, _ in cases[:2])
     for g, oracle, tris in cases:
         for name, (o, d) in all_ray_sets(tris, 20000).items():
             want = oracle.raycast(o, d)

@@ -90,15 +90,15 @@ def test_host_tree_and_lane_walk(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MESH_NAMES)
-@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW", "PT_LEAFWISE"])
+@pytest.mark.parametrize("option", ["", "PT_QNODES", "PT_DENSE_SHADOW", "PT_LEAFWISE", "PT_LEAFWISE+PT_QNODES"])
 def test_gpu_matches_oracle(name, option, monkeypatch):
-    """option: the any-hit walks on quantised interior nodes, with deferred dense triangle tests, or
-    with leaves tested by the whole wave (=2: the closest-hit walks too)."""
+    """option: the any-hit walks on quantised interior nodes, with deferred dense triangle tests, with
+    leaves tested by the whole wave, or the last with its any-hit walks on quantised interior nodes."""
     tris, scale = hostile_meshes()[name]
     host = pta.HostScene(tris)
     oracle = orc.Scene(tris)
-    if option:
-        monkeypatch.setenv(*(option.split("=") if "=" in option else (option, "1")))
+    for name_value in filter(None, option.split("+")):
+        monkeypatch.setenv(*(name_value.split("=") if "=" in name_value else (name_value, "1")))
     gpu = pta.GpuScene(host, 0)
     some_hit = False
     for rname, (o, d) in ray_sets(tris, scale).items():
