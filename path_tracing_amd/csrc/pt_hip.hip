@@ -1698,6 +1698,7 @@ struct pt_scene {
     uint32_t* d_spill2 = nullptr;
     size_t spill_bytes = 0;
     hipEvent_t ev_order = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   /* PT_OVERLAP_SHADOW: a depth's shadow traces on the second stream */
     uint32_t* d_defer = nullptr; /* deferred shadow rays of pt_raycast_shadow_dev */
     uint64_t defer_cap = 0;
     int grid_closest = 0, grid_any = 0, grid_dense = 0; /* resident blocks of the persistent trace kernels */
@@ -1976,6 +1977,8 @@ void pt_scene_destroy(pt_scene* s) {
     if (s->d_pick) (void)hipFree(s->d_pick);
     if (s->h_pick) (void)hipHostFree(s->h_pick);
     if (s->ev_order) (void)hipEventDestroy(s->ev_order);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -2462,6 +2465,22 @@ static int enqueue_bounces(pt_scene* s, RenderBuffers& b, const LaunchCtx& ctx, 
     /* PT_TRACE_ALL_SHADOW=1: trace the shadow rays of zero-weight light samples too (same picture; for checks) */
     const char* all_env = getenv("PT_TRACE_ALL_SHADOW");
     const int trace_all = (all_env && atoi(all_env) != 0) ? 1 : 0;
+    /* PT_OVERLAP_SHADOW=1 (an experiment, off by default): the shadow traces of depth d run on the scene's
+     * second stream beside the closest-hit trace of depth d+1 -- both need only k_shade(d) -- and
+     * k_shade(d+1), which reads their answers and refills their queue, waits for them.  Measured on
+     * MI355X: see the overlap entry of the tuning notes (the two persistent grids share the compute
+     * units; nothing is gained). */
+    const char* ov_env = getenv("PT_OVERLAP_SHADOW");
+    bool overlap = ov_env && atoi(ov_env) == 1 && st == s->stream && n_lights > 0;
+    LaunchCtx side = ctx;
+    if (overlap) {
+        int rc = ensure_second_lane(s);
+        if (rc) return rc;
+        if (!s->ev_fork) HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        if (!s->ev_join) HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        side = LaunchCtx{s->stream2, s->d_spill2};
+    }
+    bool join_pending = false;
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         const int cur = depth & 1;
         TraceArgs a{};
@@ -2471,6 +2490,7 @@ static int enqueue_bounces(pt_scene* s, RenderBuffers& b, const LaunchCtx& ctx, 
         a.out_hit = b.hit;
         int rc = launch_trace<TRACE_CLOSEST_FLAT>(s, a, &ctx);
         if (rc) return rc;
+        if (join_pending) { HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0)); join_pending = false; }   /* the previous depth's shadow answers */
         {
             ScopedTimer tm(s, PT_KERNEL_SHADE, st);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(STREAM_BLOCK), 0, st, s->d, cam, d_lights, n_lights, depth,
@@ -2485,18 +2505,24 @@ static int enqueue_bounces(pt_scene* s, RenderBuffers& b, const LaunchCtx& ctx, 
             sa.target = b.sh_target;
             sa.d_next_chunk = b.cnt + CNT_CHUNK(1, depth);
             sa.dist = b.sh_dist; sa.vis = b.sh_vis[cur];
+            if (overlap) { HIP_TRY(hipEventRecord(s->ev_fork, st)); HIP_TRY(hipStreamWaitEvent(side.stream, s->ev_fork, 0)); }
             if (cam.shadow_mode == PT_SHADOW_BOUNDED) {
-                rc = launch_trace<TRACE_SHADOW_BOUNDED>(s, sa, &ctx);
+                rc = launch_trace<TRACE_SHADOW_BOUNDED>(s, sa, &side);
                 if (rc) return rc;
             } else {
                 sa.defer_list = b.sh_defer; sa.defer_count = b.cnt + CNT_DEFER + depth;
-                rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &ctx);
+                rc = launch_trace<TRACE_SHADOW_ANY>(s, sa, &side);
                 if (rc) return rc;
                 sa.d_count = b.cnt + CNT_DEFER + depth;
                 sa.count_mul = 1;
                 sa.d_next_chunk = b.cnt + CNT_CHUNK(2, depth);
-                rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &ctx);
+                rc = launch_trace<TRACE_SHADOW_EXACT>(s, sa, &side);
                 if (rc) return rc;
+            }
+            if (overlap) {
+                HIP_TRY(hipEventRecord(s->ev_join, side.stream));
+                join_pending = true;
+                if (depth == max_depth) { HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0)); join_pending = false; }
             }
             if (depth == max_depth) { /* the other depths' samples are added by the next depth's k_shade */
                 ScopedTimer tm(s, PT_KERNEL_ACCUMULATE, st);

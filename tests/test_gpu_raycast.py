@@ -149,6 +149,31 @@ def test_lambertian_render_matches_oracle(scene_small):
         film.render(pta.cli_camera(bounce_mode=7), pta.cli_lights(), [(0, 0, -1, -1, 0, 1)], seed=6)
 
 
+@pytest.mark.parametrize("shadow_mode", [0, 1])
+def test_shadow_traces_beside_the_next_closest_hit_trace(scene_medium, monkeypatch, shadow_mode):
+    """PT_OVERLAP_SHADOW=1 runs the shadow traces of depth d on a second stream beside the closest-hit
+    trace of depth d+1 (an option).  Same film bit for bit, same ray counts, several batches in a row,
+    in both shadow modes, and against the oracle."""
+    sc = scene_medium
+    W, H, S = 256, 128, 6
+    cam = pta.cli_camera(dof_aperture=0.1, dof_distance=4.5, shadow_mode=shadow_mode)
+    film = pta.Film(sc.gpu, W, H)
+    monkeypatch.setenv("PT_BATCH_PATHS", str(W * H * 2))   # three batches per call
+    st1 = film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=5)
+    plain, p1 = film.read()
+    film.zero()
+    monkeypatch.setenv("PT_OVERLAP_SHADOW", "1")
+    st2 = film.render(cam, pta.cli_lights(), [(0, 0, -1, -1, 0, S)], seed=5)
+    beside, p2 = film.read()
+    assert (p1 == S).all() and np.array_equal(p1, p2)
+    assert (st1.closest_rays, st1.shadow_rays, st1.shadow_rays_traced) == (st2.closest_rays, st2.shadow_rays, st2.shadow_rays_traced)
+    assert np.array_equal(plain.view(np.uint32), beside.view(np.uint32))
+    want_rgb, want_p, counts = sc.oracle.render(orc.cli_camera(dof_aperture=0.1, dof_distance=4.5, shadow_mode=shadow_mode), orc.cli_lights(),
+                                                W, H, None, 0, S, seed=5)
+    assert st2.closest_rays == int(counts[0]) and st2.shadow_rays == int(counts[1])
+    assert (np.abs(beside - want_rgb) <= 1e-5 * np.maximum(np.abs(want_rgb), 1.0)).all()
+
+
 def test_two_render_lanes_match_one(scene_small, monkeypatch):
     """PT_RENDER_LANES=2 keeps two batches in flight on two streams.  Cut into the same four
     batches, the two-lane render must leave the very same film and ray counts as the one-lane
