@@ -114,7 +114,8 @@ struct RaySoAW {
 #error "the early stack reads serve one pop per round"
 #endif
 #ifndef SHADE_GRID_MUL
-#define SHADE_GRID_MUL 8   /* workgroups per CU of the shade kernel's grid (2 / 4 / 8 / 16: 33.7 / 33.2 / 30.6 / 29.6 ms) */
+#define SHADE_GRID_MUL 16  /* workgroups per CU of the shade kernel's grid (2 / 4 / 8 / 16: 33.7 / 33.2 / 30.6 / 29.6 ms per step on an
+                              earlier kernel; 8 / 16 / 32 on the final one: 32.9 / 31.2 / 30.8 ms) */
 #endif
 #ifndef TRACE_MIN_CHUNKS_PER_WAVE
 #define TRACE_MIN_CHUNKS_PER_WAVE 16u /* chunks grow only while every wave still gets this many on average */
