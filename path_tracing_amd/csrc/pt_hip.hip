@@ -85,7 +85,10 @@ struct RaySoAW {
     float *ox, *oy, *oz, *dx, *dy, *dz;
 };
 
-#define TRACE_BLOCK 256
+#ifndef TRACE_BLOCK
+#define TRACE_BLOCK 256    /* threads per workgroup of the trace kernels (128 / 256 / 512 measured: see the tuning notes) */
+#endif
+#define TRACE_MAX_BLOCKS_PER_CU (2048 / TRACE_BLOCK)   /* 32 waves per CU */
 #define STACK_MAX_CLOSEST (3 * PT_MAX_TREE_DEPTH) /* worst case of the closest-hit walk */
 #define STACK_MAX_ANYHIT (PT_MAX_TREE_DEPTH)
 #ifndef STACK_LDS
@@ -2071,21 +2074,21 @@ static int init_trace_launch(pt_scene* s) {
     int per_cu_d = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_shadow_dense<DENSE_RAYS_PER_LANE>, TRACE_BLOCK, 0));
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_d = v; }
-    per_cu_d = std::max(1, std::min(per_cu_d, 8));
+    per_cu_d = std::max(1, std::min(per_cu_d, TRACE_MAX_BLOCKS_PER_CU));
     s->grid_dense = std::max(8, (s->num_cus * per_cu_d) & ~7);
     int per_cu_l = 0;
     if (s->use_qnodes_leafwise) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_trace<TRACE_SHADOW_ANY, 0, true>, TRACE_BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, k_trace<TRACE_SHADOW_ANY, 0>, TRACE_BLOCK, 0));
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_l = v; }
-    per_cu_l = std::max(1, std::min(per_cu_l, 8));
+    per_cu_l = std::max(1, std::min(per_cu_l, TRACE_MAX_BLOCKS_PER_CU));
     s->grid_leafwise = std::max(8, (s->num_cus * per_cu_l) & ~7);
     int per_cu_lc = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lc, k_trace<TRACE_CLOSEST_FLAT, 0>, TRACE_BLOCK, 0));
     if (const char* e = getenv("PT_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) per_cu_lc = v; }
-    per_cu_lc = std::max(1, std::min(per_cu_lc, 8));
+    per_cu_lc = std::max(1, std::min(per_cu_lc, TRACE_MAX_BLOCKS_PER_CU));
     s->grid_leafwise_closest = std::max(8, (s->num_cus * per_cu_lc) & ~7);
-    per_cu_c = std::max(1, std::min(per_cu_c, 8));
-    per_cu_a = std::max(1, std::min(per_cu_a, 8));
+    per_cu_c = std::max(1, std::min(per_cu_c, TRACE_MAX_BLOCKS_PER_CU));
+    per_cu_a = std::max(1, std::min(per_cu_a, TRACE_MAX_BLOCKS_PER_CU));
     /* a multiple of 8: the kernels deal their queue to the 8 XCDs by workgroup number */
     s->grid_closest = std::max(8, (s->num_cus * per_cu_c) & ~7);
     s->grid_any = std::max(8, (s->num_cus * per_cu_a) & ~7);
