@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--lambertian", action="store_true",
                     help="the flagged Lambertian bounce mode (reference integrator.cpp:79-84 without :104) instead of mirror bounces")
+    ap.add_argument("--dist-one-rank", action="store_true",
+                    help="with one rank, still set up the process group and go through every collective of the N-rank path "
+                         "(RCCL with a single member): exercises the nccl calls on a one-GPU box")
     ap.add_argument("--rehearse", action="store_true",
                     help="run the N-rank code path on ONE GPU: gloo backend, every rank on device 0, films reduced through host copies")
     return ap.parse_args()
@@ -154,11 +157,18 @@ def main():
 
     device = 0 if args.rehearse else local_rank
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.dist_one_rank
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:      # one rank started by hand
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
         if args.rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
     def note(msg):
         # progress on stderr: big scenes spend minutes before the first kernel
@@ -167,7 +177,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,7 +199,7 @@ def main():
 
     def reduce_to_rank0():
         """Canvas::add_from over all workers (canvas.cpp:47-52): one sum-reduce of the film."""
-        if world == 1:
+        if not use_dist:
             return
         if args.rehearse:
             h = film_t.cpu()
@@ -234,7 +244,7 @@ def main():
 
     def all_sum(values):
         t = torch.tensor([float(v) for v in values], dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             if not args.rehearse:
                 t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -242,7 +252,7 @@ def main():
 
     def all_max(value):
         t = torch.tensor([float(value)], dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             if not args.rehearse:
                 t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -501,7 +511,7 @@ def main():
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

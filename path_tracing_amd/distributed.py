@@ -29,6 +29,6 @@ def reduce_film(film_tensor, dst: int = 0):
     integers stored as floats, so their sum is exact; colour sums depend on the reduction
     order in the last bits, as any float sum over ranks does."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # (a group of one is a valid, if trivial, reduce)
         dist.reduce(film_tensor, dst=dst, op=dist.ReduceOp.SUM)
     return film_tensor

@@ -40,3 +40,17 @@ def test_bench_rank_failure_is_reported():
     res = _bench("--gpus", "2", "--rehearse", env={"PT_HIP_LIB": "/nonexistent/libpt_hip.so"})
     assert res.returncode != 0
     assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_collectives_over_rccl_with_one_rank():
+    """`--dist-one-rank`: the process group is set up with the `nccl` backend (RCCL) for the single rank
+    and the film reduce, the sums and maxima over ranks and the barriers all go through it -- the calls
+    the N-GPU run makes, on the one GPU of the test box."""
+    res = _bench("--gpus", "1", "--dist-one-rank")
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["film_check"] is True and out["strong_scaling"]["film_check"] is True
+    assert "RCCL" in out["config"]["parallelism"]
+    assert out["camera_samples"] == 8 * 320 * 200
