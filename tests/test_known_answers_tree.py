@@ -170,3 +170,37 @@ def test_visit_order_known_answers_gpu(monkeypatch):
     reps = 4096
     got = pta.GpuScene(host, 0).raycast_closest(np.tile(o, (reps, 1)), np.tile(d, (reps, 1)))
     check_hits(got, [np.tile(w, reps) for w in want], "GPU closest hit, 24 576 rays")
+
+
+# ---------------------------------------------------------------------------------------------------
+# FOLD: per-triangle data (Triangle::Triangle, utils.cpp:116-129; compute_barycentric_normals,
+# stlreader.cpp:62-81; set_normals, utils.cpp:131-135).
+#   A = (0,0,0) (1,0,0) (0,1,0): edge01 x edge02 = (0,0,1)
+#   B = (0,0,0) (0,0,-1) (0,1,0): edge01 = (0,0,-1), edge02 = (0,1,0), cross = (1,0,0)
+#   C = (5,5,2) (6,5,2) (5,6,2): normal (0,0,1), shares no vertex; plane parameter (2 + 2 + 2) / 3 = 2
+# A and B share the vertices (0,0,0) and (0,1,0) bit for bit: their vertex normal there is
+# normalize((0,0,1) + (1,0,0)) = (s, 0, s) with s = 1 / sqrt(2) rounded as binary32 does it (the squared
+# length 2 is exact, one square root, one division per component); the other vertices keep their
+# triangle's own normal.  base_normal = n0, u_normal = n1 - n0, v_normal = n2 - n0.
+FOLD = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, -1, 0, 1, 0], [5, 5, 2, 6, 5, 2, 5, 6, 2]], np.float32)
+
+
+def test_triangle_data_known_answers():
+    s = np.float32(1.0) / np.sqrt(np.float32(2.0))
+    one = np.float32(1.0)
+    want = np.zeros((3, 30), np.float32)
+    #            p0         p1          p2         edge01      edge02      normal     base_n     u_n               v_n        plane
+    want[0, :28] = [0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, s, 0, s, -s, 0, one - s, 0, 0, 0, 0]
+    want[1, :28] = [0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, -1, 0, 1, 0, 1, 0, 0, s, 0, s, one - s, 0, -s, 0, 0, 0, 0]
+    want[2, :28] = [5, 5, 2, 6, 5, 2, 5, 6, 2, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 2]
+    for who, make in builders():
+        got = make(FOLD).triangle_data()
+        assert np.array_equal(got, want), (who, got - want)
+    # the same through a binary STL file (the file's own normals are ignored, stlreader.cpp:30-34)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "fold.stl")
+        pta.meshgen.write_stl(path, FOLD)
+        assert np.array_equal(pta.HostScene(stl_path=path).triangle_data(), want)
+        assert np.array_equal(orc.Scene(stl_path=path).triangle_data(), want)
