@@ -204,3 +204,41 @@ def test_triangle_data_known_answers():
         pta.meshgen.write_stl(path, FOLD)
         assert np.array_equal(pta.HostScene(stl_path=path).triangle_data(), want)
         assert np.array_equal(orc.Scene(stl_path=path).triangle_data(), want)
+
+
+# ---------------------------------------------------------------------------------------------------
+# PassDescriptor::clamp_bounds (integrator.cpp:164-183) on a 10 x 6 frame, by hand:
+#   (-3,-3, 5, 5): the start is clamped to (0,0), the size is NOT shortened by the 3 pixels that hung
+#                  over (5 <= 10 - 0): columns 0..4, rows 0..4
+#   (8, 4, 1000, 1000): size cut to what is left, 2 x 2: columns 8..9, rows 4..5
+#   (20, 20, 3, 3): the start is clamped to the last pixel (9,5), size 1 x 1
+#   (2, 1, -1, -1): -1 means the frame's size, then cut: columns 2..9, rows 1..5
+# Each rectangle gets one sample; the pass counts below are the sums.
+CLAMP_RECTS = [(-3, -3, 5, 5), (8, 4, 1000, 1000), (20, 20, 3, 3), (2, 1, -1, -1)]
+
+
+def clamp_counts():
+    want = np.zeros((6, 10), np.int32)
+    want[0:5, 0:5] += 1
+    want[4:6, 8:10] += 1
+    want[5, 9] += 1
+    want[1:6, 2:10] += 1
+    return want
+
+
+def test_clamp_bounds_known_answers_oracle():
+    scene = orc.Scene(TEN)
+    rgb = np.zeros((6, 10, 3), np.float32)
+    passes = np.zeros((6, 10), np.int32)
+    for k, r in enumerate(CLAMP_RECTS):
+        scene.render(orc.cli_camera(), [], 10, 6, r, k, 1, seed=1, rgb=rgb, passes=passes)
+    assert np.array_equal(passes, clamp_counts())
+
+
+@pytest.mark.gpu
+def test_clamp_bounds_known_answers_gpu():
+    film = pta.Film(pta.GpuScene(pta.HostScene(TEN), 0), 10, 6)
+    st = film.render(pta.cli_camera(), [], [r + (k, 1) for k, r in enumerate(CLAMP_RECTS)], seed=1)
+    _, passes = film.read()
+    assert np.array_equal(passes, clamp_counts())
+    assert st.camera_samples == int(clamp_counts().sum())
