@@ -50,6 +50,20 @@ $(PKG)/bin/animate: $(PKG)/host/animate.cpp include/pt_render.h $(LIBDIR)/libpt_
 
 # Lane-level emulation of the device traversal on the CPU (tests only).
 native-tests: tests/native/_build/libtraverse_emul.so tests/native/_build/libpt_hip_smallstack.so tests/native/_build/api_check
+# Where the reference's tree is at hand: its own example front ends (main.cpp, animate.cpp), compiled
+# UNMODIFIED from where they lie -- read from standard input, so that their `#include "integrator.h"` /
+# `"visualizer.h"` find the two forwarding headers written here (one line each: #include "pt_render.h",
+# the include swap a maintainer makes) -- and linked against the libraries above.  The drop-in check of
+# the C++ surface; outputs stay in the (git-ignored) build directory.
+REF ?= /root/reference
+ifneq ($(wildcard $(REF)/main.cpp),)
+native-tests: tests/native/_build/ref_main tests/native/_build/ref_animate
+tests/native/_build/ref_%: $(REF)/%.cpp include/pt_render.h $(LIBDIR)/libpt_render.so
+	mkdir -p tests/native/_build/fwd
+	echo '#include "pt_render.h"' > tests/native/_build/fwd/integrator.h
+	echo '#include "pt_render.h"' > tests/native/_build/fwd/visualizer.h
+	$(CXX) $(HOSTFLAGS) -iquote tests/native/_build/fwd -x c++ - -o $@ -L$(LIBDIR) -lpt_render -lpt_host -lpt_hip -lz -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -Wl,-rpath-link,$(ROCM)/lib < $<
+endif
 # Exercises the C++ API directly (tests/test_gpu_cpp_api.py).
 tests/native/_build/api_check: tests/native/api_check.cpp include/pt_render.h $(LIBDIR)/libpt_render.so
 	mkdir -p tests/native/_build

@@ -7,7 +7,8 @@
  *
  *   Vec / Color / Real, Ray, Triangle, Light, Scene, kdTree, PassDescriptor, Canvas,
  *   Integrator, RenderEngine, ProgressReporter / ProgressBar,
- *   override_thread_count, get_optimal_thread_count, format_seconds_as_hms, rays_cast.
+ *   override_thread_count, get_optimal_thread_count, format_seconds_as_hms, rays_cast, triangle_tests,
+ *   start_performance_counter, print_performance_counter.
  *
  * Differences that a caller can observe:
  *   - Workers are GPUs, not CPU threads: get_optimal_thread_count() is the number of
@@ -93,6 +94,10 @@ struct Triangle { /* utils.h:94-113; filled by the scene loader */
 };
 
 extern long long rays_cast; /* kdtree.h:15: closest-hit plus shadow casts, summed over all GPUs */
+extern long long triangle_tests; /* utils.h:12: the reference never counts (utils.cpp:139 is commented out); stays 0 here too */
+
+void start_performance_counter();   /* utils.cpp:217-229: a wall-clock stopwatch; print_... writes the seconds to cout */
+void print_performance_counter();
 
 void override_thread_count(int thread_count);
 int get_optimal_thread_count();

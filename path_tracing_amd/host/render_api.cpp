@@ -24,6 +24,11 @@
 using namespace std;
 
 long long rays_cast = 0;
+long long triangle_tests = 0;
+
+static std::chrono::steady_clock::time_point g_perf_counter_start;
+void start_performance_counter() { g_perf_counter_start = std::chrono::steady_clock::now(); }
+void print_performance_counter() { cout << std::chrono::duration<double>(std::chrono::steady_clock::now() - g_perf_counter_start).count(); }
 
 /* ------------------------------------------------------------------- utils */
 
