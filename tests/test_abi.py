@@ -33,3 +33,13 @@ def test_record_sizes_match_header():
     assert C.sizeof(native.FlatNode) == 64
     assert native.NODE_DTYPE.itemsize == 64 and native.ISECT_DTYPE.itemsize == 48 and native.SHADE_DTYPE.itemsize == 64
     assert C.sizeof(native.Camera) == 17 * 4 and C.sizeof(native.Light) == 24 and C.sizeof(native.TilePass) == 24
+
+
+def test_cpp_surface_matches_the_reference_headers():
+    """tests/native/surface_probe.cpp names every public member and function that the reference's
+    integrator.h, canvas.h, kdtree.h, utils.h and visualizer.h (without the SDL display) offer to a front
+    end and asserts, at compile time, that include/pt_render.h declares each with the reference's type."""
+    import subprocess
+    res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "tests", "native", "surface_probe.cpp")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-3000:]
