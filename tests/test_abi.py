@@ -43,3 +43,20 @@ def test_cpp_surface_matches_the_reference_headers():
     res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
                           os.path.join(ROOT, "tests", "native", "surface_probe.cpp")], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-3000:]
+
+
+def test_c_abi_headers_are_plain_c():
+    """include/pt_hip.h and include/pt_host.h are what a cgo / JNI / ctypes binding reads: they compile as
+    strict C99 on their own, and a C program that calls through them links against the libraries."""
+    import subprocess
+    import tempfile
+    for header in ("pt_hip.h", "pt_host.h"):
+        res = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-x", "c", "-"],
+                             input='#include "%s"\n' % header, capture_output=True, text=True, timeout=60)
+        assert res.returncode == 0, res.stderr[-2000:]
+    prog = '#include "pt_hip.h"\n#include "pt_host.h"\nint main(void) { int n = 0; (void)pt_device_count(&n); return pt_last_error() == 0; }\n'
+    with tempfile.TemporaryDirectory() as tmp:
+        res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-x", "c", "-", "-o", os.path.join(tmp, "c_caller"),
+                              "-L" + os.path.dirname(native.HIP_LIB), "-lpt_hip", "-lpt_host", "-Wl,-rpath-link,/opt/rocm/lib"],
+                             input=prog, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr[-2000:]
