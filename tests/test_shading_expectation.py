@@ -25,19 +25,45 @@ HIT = np.array([-1.0, -2.0, 1e-3])                             # the hit point l
 N_RAYS = 1 << 17
 
 
-def expectation():
-    """Sum over the lights of E[colour / dist^2 * (c + c^16)], c = to_light.z / dist, displacement ~ N(0, 0.2^2 I)."""
+def expectation(hit=HIT, normal=(0.0, 0.0, 1.0), reflection=(0.0, 0.0, 1.0)):
+    """Sum over the lights of E[colour / dist^2 * (max(0, n.l) + max(0, r.l)^16)], l = to_light / dist,
+    to_light = displacement + light - hit, displacement ~ N(0, 0.2^2 I)."""
     x, w = np.polynomial.hermite_e.hermegauss(40)              # weight exp(-x^2 / 2)
     w = w / np.sqrt(2 * np.pi)
     zx, zy, zz = np.meshgrid(x, x, x, indexing="ij")
     ww = w[:, None, None] * w[None, :, None] * w[None, None, :]
     total = np.zeros(3)
     for pos, colour in orc.cli_lights():
-        tl = [0.2 * z + p - h for z, p, h in zip((zx, zy, zz), pos, HIT)]
+        tl = [0.2 * z + p - h for z, p, h in zip((zx, zy, zz), pos, hit)]
         dist = np.sqrt(tl[0] ** 2 + tl[1] ** 2 + tl[2] ** 2)
-        c = np.maximum(0.0, tl[2] / dist)
-        total += np.array(colour) * np.sum(ww * (c + c ** 16) / dist ** 2)
+        lambert = np.maximum(0.0, sum(n * t for n, t in zip(normal, tl)) / dist)
+        phong = np.maximum(0.0, sum(r * t for r, t in zip(reflection, tl)) / dist)
+        total += np.array(colour) * np.sum(ww * (lambert + phong ** 16) / dist ** 2)
     return total
+
+
+# The folded pair of tests/test_known_answers_tree.py: A = (0,0,0) (1,0,0) (0,1,0) has the vertex normals
+# (s,0,s), (0,0,1), (s,0,s), s = 1/sqrt(2) (its neighbour B hangs below the plane and is in no ray's way).
+# A ray straight down onto (0.5, 0.25, 0) has u = 0.5, v = 0.25: the interpolated normal is
+# normalize(n0 + u (n1 - n0) + v (n2 - n0)) = normalize((s/2, 0, s/2 + 1/2)) (integrator.cpp:66-67), the
+# mirror direction normalize(d - 2 (n.d) n) (:73-74), the hit point is lifted along the GEOMETRIC normal (:72).
+FOLD = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, -1, 0, 1, 0]], np.float32)
+
+
+def fold_frame():
+    s = 1.0 / np.sqrt(2.0)
+    n = np.array([s / 2, 0.0, s / 2 + 0.5])
+    n /= np.linalg.norm(n)
+    d = np.array([0.0, 0.0, -1.0])
+    r = d - 2 * n.dot(d) * n
+    r /= np.linalg.norm(r)
+    return np.array([0.5, 0.25, 1e-3]), n, r
+
+
+def fold_rays():
+    o = np.tile(np.array([[0.5, 0.25, 5.0]], np.float32), (N_RAYS, 1))
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (N_RAYS, 1))
+    return o, d
 
 
 def rays():
@@ -46,8 +72,8 @@ def rays():
     return o, d
 
 
-def check_mean(rgb, who):
-    want = expectation()
+def check_mean(rgb, who, want=None):
+    want = expectation() if want is None else want
     got = rgb.astype(np.float64).mean(axis=0)
     err = rgb.astype(np.float64).std(axis=0) / np.sqrt(len(rgb))
     assert (np.abs(got - want) < 5 * err + 1e-4 * want).all(), (who, got, want, err)
@@ -60,6 +86,13 @@ def test_light_loop_expectation_oracle():
     rgb, counts = scene.cast_rays(orc.make_camera((0, 0, 0), (1, 0, 0)), orc.cli_lights(), o, d, recursions=10)
     assert list(counts[:2]) == [2 * N_RAYS, 3 * N_RAYS]       # one bounce ray that leaves, three shadow casts
     check_mean(rgb, "oracle")
+    # interpolated normal and mirror direction
+    o, d = fold_rays()
+    rgb, counts = orc.Scene(FOLD).cast_rays(orc.make_camera((0, 0, 0), (1, 0, 0)), orc.cli_lights(), o, d, recursions=10)
+    assert list(counts[:2]) == [2 * N_RAYS, 3 * N_RAYS]
+    check_mean(rgb, "oracle, folded pair", expectation(*fold_frame()))
+    flat = expectation(fold_frame()[0])
+    assert (np.abs(expectation(*fold_frame()) - flat) > 0.02 * flat).all(), "the tilt of the normal matters at this point"
 
 
 def test_unbounded_shadow_rays_oracle():
@@ -79,6 +112,9 @@ def test_light_loop_expectation_gpu():
     rgb, st = gpu.cast_rays(pta.make_camera((0, 0, 0), (1, 0, 0)), pta.cli_lights(), o, d, recursions=10)
     assert (st.closest_rays, st.shadow_rays) == (2 * N_RAYS, 3 * N_RAYS)
     check_mean(rgb, "GPU")
+    o2, d2 = fold_rays()
+    rgb, _ = pta.GpuScene(pta.HostScene(FOLD), 0).cast_rays(pta.make_camera((0, 0, 0), (1, 0, 0)), pta.cli_lights(), o2, d2, recursions=10)
+    check_mean(rgb, "GPU, folded pair", expectation(*fold_frame()))
     gpu = pta.GpuScene(pta.HostScene(np.array([BIG_FLOOR, CEILING], np.float32)), 0)
     rgb, _ = gpu.cast_rays(pta.make_camera((0, 0, 0), (1, 0, 0)), pta.cli_lights(), o[:4096], d[:4096], recursions=10)
     assert not rgb.any()
