@@ -120,3 +120,40 @@ def test_light_loop_expectation_gpu():
     assert not rgb.any()
     rgb, _ = gpu.cast_rays(pta.make_camera((0, 0, 0), (1, 0, 0), shadow_mode=1), pta.cli_lights(), o[:4096], d[:4096], recursions=10)
     assert (rgb > 0).all()
+
+
+# Two small facing patches, a floor piece (normal +z) and a ceiling piece (normal -z: the other winding),
+# around the vertical through (-1, -2): a ray straight down bounces between them until its 10 recursions
+# are used up (integrator.cpp:76, :107, :261) -- 11 path vertices, each lit by the three lights (no shadow
+# ray meets a patch: they are half a unit wide and the lights are far off the vertical), the k-th weighted
+# 0.8^k.  So the expectation is E_floor (1 + 0.8^2 + ... + 0.8^10) + E_ceiling (0.8 + 0.8^3 + ... + 0.8^9).
+PATCHES = np.array([[-1.25, -2.25, 0, -0.25, -2.25, 0, -1.25, -1.25, 0],
+                    [-1.25, -2.25, 6, -1.25, -1.25, 6, -0.25, -2.25, 6]], np.float32)
+
+
+def bounce_series_expectation():
+    e_floor = expectation(np.array([-1.0, -2.0, 1e-3]), (0.0, 0.0, 1.0), (0.0, 0.0, 1.0))
+    e_ceiling = expectation(np.array([-1.0, -2.0, 6.0 - 1e-3]), (0.0, 0.0, -1.0), (0.0, 0.0, -1.0))
+    return e_floor * sum(0.8 ** k for k in range(0, 11, 2)) + e_ceiling * sum(0.8 ** k for k in range(1, 11, 2))
+
+
+def test_bounce_series_oracle():
+    o, d = rays()
+    rgb, counts = orc.Scene(PATCHES).cast_rays(orc.make_camera((0, 0, 0), (1, 0, 0)), orc.cli_lights(), o, d, recursions=10)
+    assert list(counts[:2]) == [11 * N_RAYS, 33 * N_RAYS]
+    check_mean(rgb, "oracle, bounce series", bounce_series_expectation())
+    # fewer recursions, fewer terms: cast_ray(ray, 2, 1) stops after three vertices
+    rgb, counts = orc.Scene(PATCHES).cast_rays(orc.make_camera((0, 0, 0), (1, 0, 0)), orc.cli_lights(), o, d, recursions=2)
+    assert list(counts[:2]) == [3 * N_RAYS, 9 * N_RAYS]
+    e_floor = expectation(np.array([-1.0, -2.0, 1e-3]))
+    e_ceiling = expectation(np.array([-1.0, -2.0, 6.0 - 1e-3]), (0.0, 0.0, -1.0), (0.0, 0.0, -1.0))
+    check_mean(rgb, "oracle, three vertices", e_floor * (1 + 0.64) + e_ceiling * 0.8)
+
+
+@pytest.mark.gpu
+def test_bounce_series_gpu():
+    o, d = rays()
+    gpu = pta.GpuScene(pta.HostScene(PATCHES), 0)
+    rgb, st = gpu.cast_rays(pta.make_camera((0, 0, 0), (1, 0, 0)), pta.cli_lights(), o, d, recursions=10)
+    assert (st.closest_rays, st.shadow_rays) == (11 * N_RAYS, 33 * N_RAYS)
+    check_mean(rgb, "GPU, bounce series", bounce_series_expectation())
