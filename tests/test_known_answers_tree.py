@@ -242,3 +242,32 @@ def test_clamp_bounds_known_answers_gpu():
     _, passes = film.read()
     assert np.array_equal(passes, clamp_counts())
     assert st.camera_samples == int(clamp_counts().sum())
+
+
+# ---------------------------------------------------------------------------------------------------
+# Work in the reference's visit order (what the bench line's algorithmic bytes are priced from): box
+# tests = calls of kdTreeNode::ray_test (each begins with its own box, kdtree.cpp:273), triangle tests =
+# iterations of the leaf loop (:281-292), counted by hand on TEN:
+#   ray 1 of ORDER_RAYS (origin inside both extents): root, low (5 triangles), high (5)             -> 3, 10
+#   ray 3 (near = high, hit at t = 1 > t_far = 1/6): root, high (5), then low (5)                    -> 3, 10
+#   origin (4.875, -0.9, 2), direction (-0.25, 0, -2): near = high, Q is hit at t = 1 <= t_far =
+#     (4 - 4.875) / -0.25 = 3.5, so the far child is never entered (:367)                            -> 2, 5
+#   origin (4.8, 50, 2) straight down: near = high, its box is hit but none of its triangles; the far
+#     child is entered because the near one missed (:393-394) and fails its own box test             -> 3, 5
+#   origin (0, 0, 5) pointing up: the root's box is behind the ray                                   -> 1, 0
+WORK_RAYS = [
+    (ORDER_RAYS[0][0], ORDER_RAYS[0][1], (3, 10)),
+    (ORDER_RAYS[2][0], ORDER_RAYS[2][1], (3, 10)),
+    ((4.875, -0.9, 2.0), (-0.25, 0.0, -2.0), (2, 5)),
+    ((4.8, 50.0, 2.0), (0.0, 0.0, -2.0), (3, 5)),
+    ((0.0, 0.0, 5.0), (0.0, 0.0, 1.0), (1, 0)),
+]
+
+
+def test_reference_order_work_counts():
+    scene = orc.Scene(TEN)
+    for o, d, want in WORK_RAYS:
+        got = scene.raycast_counts(np.array([o], np.float32), np.array([d], np.float32))
+        assert got == want, (o, d, got, want)
+    idx, t, _, _ = scene.raycast(np.array([WORK_RAYS[2][0]], np.float32), np.array([WORK_RAYS[2][1]], np.float32))
+    assert (int(idx[0]), float(t[0])) == (IDX_Q, 1.0)
